@@ -1,0 +1,300 @@
+"""ctypes binding of libaruco_slam_hip.so (include/aruco_slam_hip.h).
+
+The product path is the hipcc/gfx950 build next to this file.  There is no CPU fallback: if the library
+is missing, or no HIP device is usable, loading / `Context()` raises.  (The parity tests may point
+ARUCO_SLAM_LIB at the CPU *emulation* build of the same sources under tests/hipemu — test
+infrastructure used only by `-m "not gpu"` tests to exercise kernel logic in the GPU-less container.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libaruco_slam_hip.so")
+
+ASLAM_OK = 0
+E_NAMES = {-1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "CAPACITY", -5: "STATE"}
+MAP_RECORD_BYTES = 104
+MARKER_MAX = 128
+CAND_MAX = 512
+
+
+class AslamInit(C.Structure):
+    _fields_ = [
+        ("Q_k", C.c_double), ("R_x", C.c_double), ("R_y", C.c_double), ("R_theta", C.c_double),
+        ("kl", C.c_double), ("kr", C.c_double), ("b", C.c_double),
+        ("marker_length", C.c_double),
+        ("markers_dictionary", C.c_int),
+        ("useful_distance_threshold", C.c_float),
+        ("r2c_t", C.c_double * 3), ("r2c_q", C.c_double * 4),
+        ("device_id", C.c_int),
+        ("max_landmarks", C.c_int),
+        ("max_rows", C.c_int), ("max_cols", C.c_int),
+        ("max_batch", C.c_int),
+        ("persistent_waves", C.c_int),
+        ("cap_starts_per_frame", C.c_uint),
+        ("cap_contours_per_frame", C.c_uint),
+        ("cap_points_per_frame", C.c_uint),
+    ]
+
+
+class AslamError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"aslam error {code} ({E_NAMES.get(code, '?')}): {msg}")
+        self.code = code
+
+
+_P = C.POINTER
+_u8p, _ip, _fp, _dp, _llp = _P(C.c_uint8), _P(C.c_int), _P(C.c_float), _P(C.c_double), _P(C.c_longlong)
+
+_SIGS = {
+    "aslam_default_init": (None, [_P(AslamInit)]),
+    "aslam_create": (C.c_int, [_P(AslamInit), _P(C.c_void_p)]),
+    "aslam_destroy": (None, [C.c_void_p]),
+    "aslam_last_error": (C.c_char_p, [C.c_void_p]),
+    "aslam_set_camera": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int]),
+    "aslam_add_encoder": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "aslam_add_image": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_size_t]),
+    "aslam_get_state": (C.c_int, [C.c_void_p, _ip, _dp, _dp]),
+    "aslam_set_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _ip]),
+    "aslam_get_detections": (C.c_int, [C.c_void_p, _ip, _ip, _fp, _dp, _dp]),
+    "aslam_get_observations": (C.c_int, [C.c_void_p, _ip, _ip, _ip, _ip, _dp, _dp]),
+    "aslam_get_landmark_ids": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "aslam_stage_frames": (C.c_int, [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t]),
+    "aslam_stage_encoders": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]),
+    "aslam_run_staged": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "aslam_sync": (C.c_int, [C.c_void_p]),
+    "aslam_get_slot_detections": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _fp, _dp, _dp]),
+    "aslam_get_slot_raw_observations": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp, _dp]),
+    "aslam_detect_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
+                                     C.c_int, _ip, _ip, _fp, _dp, _dp]),
+    "aslam_export_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "aslam_debug_get_nbr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p]),
+    "aslam_debug_get_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, _ip, _ip, _ip, _ip, _llp]),
+    "aslam_debug_get_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _ip, _fp, _ip, _ip]),
+    "aslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "aslam_profile_reset": (C.c_int, [C.c_void_p]),
+    "aslam_profile_get": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_char_p), _ip, _dp]),
+    "aslam_synth_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _ip, _dp, C.c_double, C.c_int,
+                                     C.c_int, C.c_uint, C.c_int, _u8p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+_lib = None
+
+
+def lib_path():
+    return os.environ.get("ARUCO_SLAM_LIB", DEFAULT_LIB)
+
+
+def load():
+    """Load the shared library (once).  Raises if it is missing — there is no fallback implementation."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise OSError(f"{path} not found: build it with `make -C aruco_slam_amd/csrc` (hipcc, gfx950)")
+        lib = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ) if a is not None else None
+
+
+def default_init(**over):
+    init = AslamInit()
+    load().aslam_default_init(C.byref(init))
+    for k, v in over.items():
+        if k in ("r2c_t", "r2c_q"):
+            for i, x in enumerate(v):
+                getattr(init, k)[i] = x
+        else:
+            setattr(init, k, v)
+    return init
+
+
+class Context:
+    """One camera stream: thin RAII wrapper over aslam_ctx (mirrors the `ArucoSlam` class surface)."""
+
+    def __init__(self, init=None, **over):
+        self.lib = load()
+        self.init = init if init is not None else default_init(**over)
+        h = C.c_void_p()
+        rc = self.lib.aslam_create(C.byref(self.init), C.byref(h))
+        if rc != ASLAM_OK:
+            raise AslamError(rc, "aslam_create failed (no usable HIP device, bad init, or out of memory)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.aslam_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != ASLAM_OK:
+            raise AslamError(rc, self.lib.aslam_last_error(self.h).decode())
+
+    # -- reference class surface ---------------------------------------------------------------
+    def set_camera(self, K, D=None):
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        D = np.zeros(0) if D is None else np.ascontiguousarray(D, dtype=np.float64).reshape(-1)
+        self._ck(self.lib.aslam_set_camera(self.h, _ptr(K, _dp), _ptr(D, _dp) if D.size else None, int(D.size)))
+
+    def add_encoder(self, wl, wr, t_now):
+        self._ck(self.lib.aslam_add_encoder(self.h, float(wl), float(wr), float(t_now)))
+
+    def add_image(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        rows, cols = img.shape[:2]
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        self._ck(self.lib.aslam_add_image(self.h, _ptr(img, _u8p), rows, cols, ch, cols * ch))
+
+    def get_state(self):
+        n = C.c_int()
+        self._ck(self.lib.aslam_get_state(self.h, C.byref(n), None, None))
+        N = n.value
+        mu = np.zeros(N)
+        sigma = np.zeros((N, N), order="F")
+        self._ck(self.lib.aslam_get_state(self.h, C.byref(n), _ptr(mu, _dp), _ptr(sigma, _dp)))
+        return mu, np.array(sigma)
+
+    def set_state(self, mu, sigma, landmark_ids):
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        sig = np.asfortranarray(sigma, dtype=np.float64)
+        ids = np.ascontiguousarray(landmark_ids, dtype=np.int32)
+        self._ck(self.lib.aslam_set_state(self.h, int(mu.size), _ptr(mu, _dp), _ptr(sig, _dp), _ptr(ids, _ip) if ids.size else None))
+
+    def _detections(self, fn, *pre):
+        m = C.c_int()
+        ids = np.zeros(MARKER_MAX, np.int32)
+        corners = np.zeros((MARKER_MAX, 4, 2), np.float32)
+        rv = np.zeros((MARKER_MAX, 3))
+        tv = np.zeros((MARKER_MAX, 3))
+        self._ck(fn(self.h, *pre, C.byref(m), _ptr(ids, _ip), _ptr(corners, _fp), _ptr(rv, _dp), _ptr(tv, _dp)))
+        M = m.value
+        return ids[:M].copy(), corners[:M].copy(), rv[:M].copy(), tv[:M].copy()
+
+    def get_detections(self):
+        return self._detections(self.lib.aslam_get_detections)
+
+    def get_slot_detections(self, slot):
+        return self._detections(self.lib.aslam_get_slot_detections, int(slot))
+
+    def get_observations(self):
+        n = C.c_int()
+        ids = np.zeros(MARKER_MAX, np.int32); idx = np.zeros(MARKER_MAX, np.int32); act = np.zeros(MARKER_MAX, np.int32)
+        xyth = np.zeros((MARKER_MAX, 3)); R = np.zeros((MARKER_MAX, 3))
+        self._ck(self.lib.aslam_get_observations(self.h, C.byref(n), _ptr(ids, _ip), _ptr(idx, _ip), _ptr(act, _ip), _ptr(xyth, _dp), _ptr(R, _dp)))
+        k = n.value
+        return ids[:k].copy(), idx[:k].copy(), act[:k].copy(), xyth[:k].copy(), R[:k].copy()
+
+    def get_slot_raw_observations(self, slot):
+        n = C.c_int()
+        ids = np.zeros(MARKER_MAX, np.int32); valid = np.zeros(MARKER_MAX, np.int32)
+        xyth = np.zeros((MARKER_MAX, 3)); R = np.zeros((MARKER_MAX, 3))
+        self._ck(self.lib.aslam_get_slot_raw_observations(self.h, int(slot), C.byref(n), _ptr(ids, _ip), _ptr(valid, _ip), _ptr(xyth, _dp), _ptr(R, _dp)))
+        k = n.value
+        return ids[:k].copy(), valid[:k].copy(), xyth[:k].copy(), R[:k].copy()
+
+    def get_landmark_ids(self):
+        n = C.c_int()
+        ids = np.zeros(max(int(self.init.max_landmarks), 1), np.int32)
+        self._ck(self.lib.aslam_get_landmark_ids(self.h, C.byref(n), _ptr(ids, _ip)))
+        return ids[: n.value].copy()
+
+    # -- staged (device-resident) stream API ------------------------------------------------------
+    def stage_frames(self, frames, slot0=0):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim == 2:
+            frames = frames[None]
+        n, rows, cols = frames.shape[:3]
+        ch = 1 if frames.ndim == 3 else frames.shape[3]
+        self._ck(self.lib.aslam_stage_frames(self.h, int(slot0), _ptr(frames, _u8p), n, rows, cols, ch, cols * ch, rows * cols * ch))
+
+    def stage_encoders(self, wl, wr, dt, slot0=0):
+        wl = np.ascontiguousarray(wl, dtype=np.float64); wr = np.ascontiguousarray(wr, dtype=np.float64)
+        dt = np.ascontiguousarray(dt, dtype=np.float64)
+        self._ck(self.lib.aslam_stage_encoders(self.h, int(slot0), int(wl.size), _ptr(wl, _dp), _ptr(wr, _dp), _ptr(dt, _dp)))
+
+    def run_staged(self, first, count, with_ekf=True):
+        self._ck(self.lib.aslam_run_staged(self.h, int(first), int(count), 1 if with_ekf else 0))
+
+    def sync(self):
+        self._ck(self.lib.aslam_sync(self.h))
+
+    def detect_batch(self, frames, max_per_frame=64):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, rows, cols = frames.shape[:3]
+        ch = 1 if frames.ndim == 3 else frames.shape[3]
+        counts = np.zeros(n, np.int32)
+        ids = np.full((n, max_per_frame), -1, np.int32)
+        corners = np.zeros((n, max_per_frame, 4, 2), np.float32)
+        rv = np.zeros((n, max_per_frame, 3)); tv = np.zeros((n, max_per_frame, 3))
+        self._ck(self.lib.aslam_detect_batch(self.h, _ptr(frames, _u8p), n, rows, cols, ch, cols * ch, rows * cols * ch,
+                                             max_per_frame, _ptr(counts, _ip), _ptr(ids, _ip), _ptr(corners, _fp), _ptr(rv, _dp), _ptr(tv, _dp)))
+        return counts, ids, corners, rv, tv
+
+    def export_map(self):
+        buf = np.zeros(int(self.init.max_landmarks) * MAP_RECORD_BYTES, np.uint8)
+        self._ck(self.lib.aslam_export_map(self.h, buf.ctypes.data_as(C.c_void_p), 0))
+        return buf
+
+    def export_map_to_device(self, device_ptr):
+        self._ck(self.lib.aslam_export_map(self.h, C.c_void_p(int(device_ptr)), 1))
+
+    # -- instrumentation ------------------------------------------------------------------------------
+    def debug_nbr(self, slot, scale, rows, cols):
+        out = np.zeros((rows, cols), np.uint8)
+        self._ck(self.lib.aslam_debug_get_nbr(self.h, int(slot), int(scale), _ptr(out, _u8p)))
+        return out
+
+    def debug_contours(self, slot, scale, max_contours=20000, max_points=4_000_000):
+        n = C.c_int(); tot = C.c_longlong()
+        sizes = np.zeros(max_contours, np.int32); keys = np.zeros(max_contours, np.int32)
+        pts = np.zeros((max_points, 2), np.int32)
+        self._ck(self.lib.aslam_debug_get_contours(self.h, int(slot), int(scale), max_contours, max_points, C.byref(n),
+                                                   _ptr(sizes, _ip), _ptr(keys, _ip), _ptr(pts, _ip), C.byref(tot)))
+        k = n.value
+        return sizes[:k].copy(), keys[:k].copy(), pts[: tot.value].copy()
+
+    def debug_candidates(self, slot, stage):
+        n = C.c_int()
+        corners = np.zeros((CAND_MAX, 4, 2), np.float32); sizes = np.zeros(CAND_MAX, np.int32); ids = np.zeros(CAND_MAX, np.int32)
+        self._ck(self.lib.aslam_debug_get_candidates(self.h, int(slot), int(stage), CAND_MAX, C.byref(n), _ptr(corners, _fp), _ptr(sizes, _ip), _ptr(ids, _ip)))
+        k = n.value
+        return corners[:k].copy(), sizes[:k].copy(), ids[:k].copy()
+
+    def profile_enable(self, on=True):
+        self._ck(self.lib.aslam_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._ck(self.lib.aslam_profile_reset(self.h))
+
+    def profile_get(self):
+        names = (C.c_char_p * 32)(); calls = np.zeros(32, np.int32); ms = np.zeros(32)
+        n = self.lib.aslam_profile_get(self.h, 32, names, _ptr(calls, _ip), _ptr(ms, _dp))
+        return {names[i].decode(): (int(calls[i]), float(ms[i])) for i in range(n)}
+
+    def synth_render(self, slot, rows, cols, K, ids, poses, marker_length=0.27, background=128, noise_amp=0, seed=0,
+                     supersample=4, download=True):
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 12)
+        out = np.zeros((rows, cols), np.uint8) if download else None
+        self._ck(self.lib.aslam_synth_render(self.h, int(slot), rows, cols, _ptr(K, _dp), int(ids.size), _ptr(ids, _ip) if ids.size else None,
+                                             _ptr(poses, _dp) if ids.size else None, float(marker_length), int(background), int(noise_amp),
+                                             int(seed), int(supersample), _ptr(out, _u8p)))
+        return out

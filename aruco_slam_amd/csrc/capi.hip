@@ -1,0 +1,743 @@
+// C-ABI of libaruco_slam_hip.so (include/aruco_slam_hip.h): context, device buffers, stream orchestration.
+// Host logic only; all arithmetic of the hot path runs in the kernels of detect.hip / pose.hip / ekf.hip.
+#include "common.h"
+#include "detect.h"
+#include "pose.h"
+#include "ekf.h"
+#include "synth.h"
+#include "../../include/aruco_slam_hip.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <algorithm>
+
+using namespace aslam;
+
+namespace {
+
+enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
+              P_EKF_T, P_EKF_UPDATE, P_COUNT };
+const char* kProfNames[P_COUNT] = {"k_threshold", "k_trace", "k_quads", "k_assemble", "k_identify", "k_pose",
+                                   "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update"};
+
+struct ProfSpan { int id; hipEvent_t a, b; };
+
+} // namespace
+
+struct aslam_ctx {
+    aslam_init init{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool have_cam = false;
+    CamParams cam{};
+    SlamParams sp{};
+
+    // staged batch
+    int rows = 0, cols = 0, channels = 0;
+    int max_batch = 0, nwaves = 0;
+    DetectCfg cfg{};
+    int last_first = 0, last_count = 0;
+
+    uint8_t* d_in = nullptr;
+    uint8_t* d_gray = nullptr;
+    uint8_t* d_nbr = nullptr;
+    unsigned long long* d_starts = nullptr;
+    Counters* d_ctr = nullptr;
+    ContourRec* d_contours = nullptr;
+    unsigned* d_points = nullptr;
+    CandRec* d_cands = nullptr;
+    unsigned* d_ncand = nullptr;
+    FinalCand* d_finals = nullptr;
+    unsigned* d_nfinal = nullptr;
+    IdentWork* d_work = nullptr;
+    unsigned long long* d_dict = nullptr;
+    Marker* d_markers = nullptr;
+    unsigned* d_nmarkers = nullptr;
+    ObsRaw* d_obs = nullptr;
+    double* d_enc = nullptr;          // per slot: wl, wr, dt
+    std::vector<double> enc_host;
+    SynthMarker* d_synth = nullptr;
+    size_t in_frame_bytes = 0, pitch = 0;
+    int dict_ms = 5, dict_n = 1024, dict_maxcorr = 0;
+    std::vector<unsigned long long> dict_cells;   // per id: (ms+2)^2 cell image incl. border (for the renderer)
+
+    EkfState ekf{};
+    double last_time = 0;
+    bool is_init = false;
+
+    bool prof_on = false;
+    std::vector<ProfSpan> spans;
+    int prof_calls[P_COUNT] = {0};
+    double prof_ms[P_COUNT] = {0};
+};
+
+namespace {
+
+int fail(aslam_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) return fail((c), ASLAM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+template <class T> hipError_t dalloc(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)); }
+
+// DICT_ARUCO_ORIGINAL from first principles: 5 rows x 2 id bits (MSB first) through the words
+// 10000 / 10111 / 01001 / 01110 (original ArUco library).  parameters.yaml:16 selects enum 16.
+void make_dict_aruco_original(std::vector<unsigned long long>& codes, std::vector<unsigned long long>& cells) {
+    static const int words[4] = {0x10, 0x17, 0x09, 0x0e};
+    const int n = 5;
+    codes.resize(1024 * 4);
+    cells.resize(1024 * 2);
+    for (int id = 0; id < 1024; id++) {
+        int B[5][5];
+        for (int y = 0; y < n; y++) {
+            int val = words[(id >> (2 * (4 - y))) & 3];
+            for (int x = 0; x < n; x++) B[y][x] = (val >> (4 - x)) & 1;
+        }
+        unsigned long long c[4] = {0, 0, 0, 0};
+        for (int row = 0; row < n; row++)
+            for (int col = 0; col < n; col++) {
+                c[0] = (c[0] << 1) | (unsigned)B[row][col];
+                c[1] = (c[1] << 1) | (unsigned)B[col][n - 1 - row];
+                c[2] = (c[2] << 1) | (unsigned)B[n - 1 - row][n - 1 - col];
+                c[3] = (c[3] << 1) | (unsigned)B[n - 1 - col][row];
+            }
+        for (int r = 0; r < 4; r++) codes[(size_t)id * 4 + r] = c[r];
+        unsigned long long lo = 0;     // 7x7 cells incl. black border, bit index = r*7 + c
+        for (int row = 0; row < n; row++)
+            for (int col = 0; col < n; col++)
+                if (B[row][col]) lo |= 1ull << ((row + 1) * 7 + col + 1);
+        cells[(size_t)id * 2] = lo;
+        cells[(size_t)id * 2 + 1] = 0;
+    }
+}
+
+void prof_begin(aslam_ctx* c, int id) {
+    if (!c->prof_on) return;
+    ProfSpan s;
+    s.id = id;
+    hipEventCreate(&s.a);
+    hipEventCreate(&s.b);
+    hipEventRecord(s.a, c->stream);
+    c->spans.push_back(s);
+}
+void prof_end(aslam_ctx* c) {
+    if (!c->prof_on) return;
+    hipEventRecord(c->spans.back().b, c->stream);
+}
+void prof_collect(aslam_ctx* c) {
+    for (ProfSpan& s : c->spans) {
+        float ms = 0;
+        hipEventSynchronize(s.b);
+        hipEventElapsedTime(&ms, s.a, s.b);
+        c->prof_calls[s.id]++;
+        c->prof_ms[s.id] += ms;
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+    }
+    c->spans.clear();
+}
+
+int configure_frames(aslam_ctx* c, int rows, int cols, int channels) {
+    if (rows <= 0 || cols <= 0 || rows > c->init.max_rows || cols > c->init.max_cols || rows > 4095 || cols > 4095)
+        return fail(c, ASLAM_E_INVALID, "frame size outside [1, max_rows x max_cols]");
+    if (channels != 1 && channels != 3) return fail(c, ASLAM_E_INVALID, "channels must be 1 (gray) or 3 (bgr8)");
+    c->rows = rows; c->cols = cols; c->channels = channels;
+    DetectCfg& g = c->cfg;
+    g.rows = rows; g.cols = cols;
+    g.pitch = (cols + 63) / 64 * 64;
+    // cv::aruco::DetectorParameters defaults of OpenCV 3.2.0 (the reference passes none, aruco_slam.cpp:313)
+    g.win_r[0] = 1; g.win_r[1] = 6; g.win_r[2] = 11;                     // windows 3, 13, 23
+    g.thresh_c = 7;
+    g.min_perim = (int)(unsigned)(0.03 * std::max(cols, rows));
+    g.max_perim = (int)(unsigned)(4.0 * std::max(cols, rows));
+    g.approx_rate = 0.05;
+    g.min_corner_rate = 0.05;
+    g.min_marker_dist_rate = 0.05;
+    g.min_border_dist = 3;
+    g.marker_size = c->dict_ms;
+    g.border_bits = 1;
+    g.cell_margin = (int)(0.13 * kCellPx);
+    g.max_border_err = (int)(c->dict_ms * c->dict_ms * 0.35);
+    g.max_corr = (int)((double)c->dict_maxcorr * 0.6);
+    g.n_dict = c->dict_n;
+    g.min_otsu_std = 5.0;
+    g.cap_starts = c->init.cap_starts_per_frame * (unsigned)c->max_batch;
+    g.cap_contours = c->init.cap_contours_per_frame * (unsigned)c->max_batch;
+    g.cap_points = c->init.cap_points_per_frame * (unsigned)c->max_batch;
+    return ASLAM_OK;
+}
+
+int check_slot_range(aslam_ctx* c, int first, int count) {
+    if (first < 0 || count <= 0 || first + count > c->max_batch) return fail(c, ASLAM_E_INVALID, "slot range outside [0, max_batch)");
+    return ASLAM_OK;
+}
+
+// detection + pose for `count` staged frames starting at slot `first` (asynchronous on the stream)
+int run_detect(aslam_ctx* c, int first, int count) {
+    if (c->rows == 0) return fail(c, ASLAM_E_STATE, "no frames staged");
+    if (!c->have_cam) return fail(c, ASLAM_E_STATE, "camera parameters not set (aslam_set_camera)");
+    hipStream_t st = c->stream;
+    const DetectCfg& g = c->cfg;
+    const size_t frame_px = (size_t)g.rows * g.cols;
+    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
+    HIP_TRY(c, hipMemsetAsync(c->d_ncand + first, 0, sizeof(unsigned) * count, st));
+    // per-frame arrays are indexed by slot: pass base pointers offset to `first`
+    prof_begin(c, P_THRESH);
+    launch_threshold(st, c->d_in + (size_t)first * c->in_frame_bytes, c->channels, c->in_frame_bytes,
+                     (size_t)g.cols * c->channels, count, c->d_gray + (size_t)first * frame_px,
+                     c->d_nbr + (size_t)first * kScales * g.rows * g.pitch, g, c->d_starts, c->d_ctr);
+    prof_end(c);
+    prof_begin(c, P_TRACE);
+    launch_trace(st, c->nwaves, c->d_nbr + (size_t)first * kScales * g.rows * g.pitch, g, c->d_starts, c->d_ctr, c->d_contours, c->d_points);
+    prof_end(c);
+    prof_begin(c, P_QUADS);
+    launch_quads(st, c->nwaves, g, c->d_ctr, c->d_contours, c->d_points, c->d_cands + (size_t)first * kCandMax, c->d_ncand + first);
+    prof_end(c);
+    prof_begin(c, P_ASSEMBLE);
+    launch_assemble(st, count, g, c->d_ctr, c->d_cands + (size_t)first * kCandMax, c->d_ncand + first,
+                    c->d_finals + (size_t)first * kCandMax, c->d_nfinal + first, c->d_work);
+    prof_end(c);
+    prof_begin(c, P_IDENTIFY);
+    launch_identify(st, c->nwaves, g, c->d_ctr, c->d_gray + (size_t)first * frame_px, c->d_finals + (size_t)first * kCandMax,
+                    c->d_work, c->d_dict);
+    prof_end(c);
+    prof_begin(c, P_POSE);
+    launch_pose(st, count, c->d_finals + (size_t)first * kCandMax, c->d_nfinal + first, c->d_markers + (size_t)first * kMarkerMax,
+                c->d_nmarkers + first, c->d_obs + (size_t)first * kMarkerMax, c->cam, c->sp, c->d_ctr);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    c->last_first = first;
+    c->last_count = count;
+    return ASLAM_OK;
+}
+
+int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool do_predict) {
+    hipStream_t st = c->stream;
+    prof_begin(c, P_EKF_PLAN);
+    launch_ekf_plan(st, c->ekf, c->sp, wl, wr, dt, do_predict ? 1 : 0, c->d_obs + (size_t)slot * kMarkerMax, c->d_nmarkers + slot, c->d_ctr);
+    prof_end(c);
+    prof_begin(c, P_EKF_GATHER);
+    launch_ekf_gather(st, c->ekf);
+    prof_end(c);
+    prof_begin(c, P_EKF_SMALL);
+    launch_ekf_small(st, c->ekf);
+    prof_end(c);
+    prof_begin(c, P_EKF_T);
+    launch_ekf_T(st, c->ekf);
+    prof_end(c);
+    prof_begin(c, P_EKF_UPDATE);
+    launch_ekf_update(st, c->ekf);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return ASLAM_OK;
+}
+
+int sync_and_check(aslam_ctx* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    Counters h{};
+    HIP_TRY(c, hipMemcpy(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.overflow) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "device list overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 candidates, 16 markers, 32 landmarks)", h.overflow);
+        return fail(c, ASLAM_E_CAPACITY, buf);
+    }
+    return ASLAM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void aslam_default_init(aslam_init* i) {
+    std::memset(i, 0, sizeof(*i));
+    i->Q_k = 0.01; i->R_x = 100; i->R_y = 100; i->R_theta = 10;          // parameters.yaml:5-8
+    i->kl = 0.05; i->kr = 0.05; i->b = 0.09;                              // parameters.yaml:11-13
+    i->marker_length = 0.27; i->markers_dictionary = 16;                  // parameters.yaml:16-17
+    i->useful_distance_threshold = 3.0f;                                  // aruco_slam.h:58
+    i->r2c_q[3] = 1.0;
+    i->device_id = 0;
+    i->max_landmarks = 256;
+    i->max_rows = 720; i->max_cols = 1280;
+    i->max_batch = 1;
+    i->persistent_waves = 0;
+    i->cap_starts_per_frame = 0; i->cap_contours_per_frame = 0; i->cap_points_per_frame = 0;
+}
+
+int aslam_create(const aslam_init* init, aslam_ctx** out) {
+    if (!init || !out) return ASLAM_E_INVALID;
+    *out = nullptr;
+    if (init->markers_dictionary != 16) return ASLAM_E_INVALID;   // only DICT_ARUCO_ORIGINAL can be generated offline
+    if (init->max_rows <= 0 || init->max_cols <= 0 || init->max_batch <= 0 || init->max_landmarks <= 0) return ASLAM_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || init->device_id >= ndev) return ASLAM_E_NO_DEVICE;
+    if (hipSetDevice(init->device_id) != hipSuccess) return ASLAM_E_NO_DEVICE;
+    aslam_ctx* c = new aslam_ctx();
+    c->init = *init;
+    if (c->init.cap_starts_per_frame == 0) c->init.cap_starts_per_frame = 1u << 17;
+    if (c->init.cap_contours_per_frame == 0) c->init.cap_contours_per_frame = 1u << 13;
+    if (c->init.cap_points_per_frame == 0) c->init.cap_points_per_frame = 1u << 19;
+    c->max_batch = init->max_batch;
+    c->nwaves = init->persistent_waves > 0 ? init->persistent_waves : 2048;
+    c->sp.Q_k = init->Q_k; c->sp.R_x = init->R_x; c->sp.R_y = init->R_y; c->sp.R_theta = init->R_theta;
+    c->sp.kl = init->kl; c->sp.kr = init->kr; c->sp.b = init->b; c->sp.marker_length = init->marker_length;
+    c->sp.r2c_tx = init->r2c_t[0]; c->sp.r2c_ty = init->r2c_t[1];
+    c->sp.useful_distance_threshold = init->useful_distance_threshold;
+
+    const int B = c->max_batch;
+    const size_t px = (size_t)init->max_rows * init->max_cols;
+    const size_t pitch = ((size_t)init->max_cols + 63) / 64 * 64;
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+    ok = ok && dalloc(&c->d_in, px * 3 * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_gray, px * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_nbr, (size_t)kScales * init->max_rows * pitch * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_starts, (size_t)c->init.cap_starts_per_frame * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_ctr, 1) == hipSuccess;
+    ok = ok && dalloc(&c->d_contours, (size_t)c->init.cap_contours_per_frame * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_points, (size_t)c->init.cap_points_per_frame * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_cands, (size_t)kCandMax * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_ncand, B) == hipSuccess;
+    ok = ok && dalloc(&c->d_finals, (size_t)kCandMax * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_nfinal, B) == hipSuccess;
+    ok = ok && dalloc(&c->d_work, (size_t)kCandMax * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_markers, (size_t)kMarkerMax * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_nmarkers, B) == hipSuccess;
+    ok = ok && dalloc(&c->d_obs, (size_t)kMarkerMax * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_enc, (size_t)3 * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_synth, 256) == hipSuccess;
+    std::vector<unsigned long long> codes;
+    make_dict_aruco_original(codes, c->dict_cells);
+    ok = ok && dalloc(&c->d_dict, codes.size()) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_dict, codes.data(), codes.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(c->d_ctr, 0, sizeof(Counters)) == hipSuccess;
+    ok = ok && hipMemset(c->d_nmarkers, 0, sizeof(unsigned) * B) == hipSuccess;
+    ok = ok && hipMemset(c->d_nfinal, 0, sizeof(unsigned) * B) == hipSuccess;
+    ok = ok && hipMemset(c->d_ncand, 0, sizeof(unsigned) * B) == hipSuccess;
+    ok = ok && hipMemset(c->d_enc, 0, sizeof(double) * 3 * B) == hipSuccess;
+    ok = ok && ekf_alloc(c->ekf, init->max_landmarks) == hipSuccess;
+    if (!ok) { aslam_destroy(c); return ASLAM_E_NO_DEVICE; }
+    *out = c;
+    return ASLAM_OK;
+}
+
+void aslam_destroy(aslam_ctx* c) {
+    if (!c) return;
+    if (c->stream) hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    hipFree(c->d_in); hipFree(c->d_gray); hipFree(c->d_nbr); hipFree(c->d_starts); hipFree(c->d_ctr);
+    hipFree(c->d_contours); hipFree(c->d_points); hipFree(c->d_cands); hipFree(c->d_ncand); hipFree(c->d_finals);
+    hipFree(c->d_nfinal); hipFree(c->d_work); hipFree(c->d_dict); hipFree(c->d_markers); hipFree(c->d_nmarkers);
+    hipFree(c->d_obs); hipFree(c->d_enc); hipFree(c->d_synth);
+    ekf_free(c->ekf);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* aslam_last_error(const aslam_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int aslam_set_camera(aslam_ctx* c, const double K[9], const double* D, int nD) {
+    if (!c || !K || nD < 0 || (nD > 0 && !D)) return fail(c, ASLAM_E_INVALID, "bad camera arguments");
+    c->cam.fx = K[0]; c->cam.fy = K[4]; c->cam.cx = K[2]; c->cam.cy = K[5];
+    c->cam.nD = std::min(nD, 5);
+    for (int i = 0; i < 5; i++) c->cam.k[i] = i < c->cam.nD ? D[i] : 0.0;
+    c->have_cam = true;
+    return ASLAM_OK;
+}
+
+int aslam_stage_frames(aslam_ctx* c, int slot0, const uint8_t* frames, int nframes, int rows, int cols, int channels,
+                       size_t step, size_t frame_stride) {
+    if (!c || !frames) return fail(c, ASLAM_E_INVALID, "null argument");
+    int r = check_slot_range(c, slot0, nframes);
+    if (r) return r;
+    if (rows != c->rows || cols != c->cols || channels != c->channels) {
+        r = configure_frames(c, rows, cols, channels);
+        if (r) return r;
+    }
+    if (step < (size_t)cols * channels) return fail(c, ASLAM_E_INVALID, "step smaller than a row");
+    c->in_frame_bytes = (size_t)rows * cols * channels;
+    for (int f = 0; f < nframes; f++)
+        HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)(slot0 + f) * c->in_frame_bytes, (size_t)cols * channels,
+                                    frames + (size_t)f * frame_stride, step, (size_t)cols * channels, rows,
+                                    hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));      // px is borrowed for the call only
+    return ASLAM_OK;
+}
+
+int aslam_stage_encoders(aslam_ctx* c, int slot0, int n, const double* wl, const double* wr, const double* dt) {
+    if (!c || !wl || !wr || !dt) return fail(c, ASLAM_E_INVALID, "null argument");
+    int r = check_slot_range(c, slot0, n);
+    if (r) return r;
+    std::vector<double> h((size_t)3 * n);
+    for (int i = 0; i < n; i++) { h[3 * i] = wl[i]; h[3 * i + 1] = wr[i]; h[3 * i + 2] = dt[i]; }
+    HIP_TRY(c, hipMemcpy(c->d_enc + (size_t)3 * slot0, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->enc_host.resize((size_t)3 * c->max_batch);
+    std::memcpy(&c->enc_host[(size_t)3 * slot0], h.data(), h.size() * sizeof(double));
+    return ASLAM_OK;
+}
+
+int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
+    if (!c) return ASLAM_E_INVALID;
+    int r = check_slot_range(c, first, count);
+    if (r) return r;
+    r = run_detect(c, first, count);
+    if (r) return r;
+    if (with_ekf) {
+        if (c->enc_host.size() < (size_t)3 * (first + count)) return fail(c, ASLAM_E_STATE, "encoders not staged");
+        for (int i = 0; i < count; i++) {
+            const double* e = &c->enc_host[(size_t)3 * (first + i)];
+            // addEncoder semantics (aruco_slam.cpp:24-29): the very first sample only arms the filter
+            bool predict = c->is_init;
+            c->is_init = true;
+            r = run_ekf_frame(c, first + i, e[0], e[1], e[2], predict);
+            if (r) return r;
+        }
+    }
+    return ASLAM_OK;
+}
+
+int aslam_sync(aslam_ctx* c) {
+    if (!c) return ASLAM_E_INVALID;
+    return sync_and_check(c);
+}
+
+int aslam_add_encoder(aslam_ctx* c, double wl, double wr, double t_now) {
+    if (!c) return ASLAM_E_INVALID;
+    if (!c->is_init) {                       // aruco_slam.cpp:24-29
+        c->last_time = t_now;
+        c->is_init = true;
+        return ASLAM_OK;
+    }
+    double dt = t_now - c->last_time;        // aruco_slam.cpp:31-32
+    c->last_time = t_now;
+    launch_ekf_predict_only(c->stream, c->ekf, c->sp, wl, wr, dt);
+    HIP_TRY(c, hipGetLastError());
+    return ASLAM_OK;
+}
+
+int aslam_add_image(aslam_ctx* c, const uint8_t* px, int rows, int cols, int channels, size_t step) {
+    if (!c || !px) return fail(c, ASLAM_E_INVALID, "null argument");
+    if (!c->is_init) return ASLAM_OK;        // aruco_slam.cpp:84-85: nothing happens before the first encoder message
+    int r = aslam_stage_frames(c, 0, px, 1, rows, cols, channels, step, 0);
+    if (r) return r;
+    r = run_detect(c, 0, 1);
+    if (r) return r;
+    r = run_ekf_frame(c, 0, 0, 0, 0, false);
+    if (r) return r;
+    return sync_and_check(c);
+}
+
+int aslam_get_state(aslam_ctx* c, int* N, double* mu, double* sigma) {
+    if (!c || !N) return fail(c, ASLAM_E_INVALID, "null argument");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int L = 0;
+    HIP_TRY(c, hipMemcpy(&L, c->ekf.d_L, sizeof(int), hipMemcpyDeviceToHost));
+    const int n = 3 + 3 * L;
+    *N = n;
+    if (mu) HIP_TRY(c, hipMemcpy(mu, c->ekf.d_mu, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (sigma) {
+        // device layout: column-major with leading dimension ld = N_max; pack to ld = N
+        std::vector<double> tmp((size_t)c->ekf.ld * n);
+        HIP_TRY(c, hipMemcpy(tmp.data(), c->ekf.d_sigma, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int col = 0; col < n; col++) std::memcpy(sigma + (size_t)col * n, &tmp[(size_t)col * c->ekf.ld], sizeof(double) * n);
+    }
+    return ASLAM_OK;
+}
+
+int aslam_set_state(aslam_ctx* c, int N, const double* mu, const double* sigma, const int* landmark_ids) {
+    if (!c || !mu || !sigma || N < 3 || (N - 3) % 3 != 0) return fail(c, ASLAM_E_INVALID, "bad state");
+    const int L = (N - 3) / 3;
+    if (L > c->ekf.max_landmarks) return fail(c, ASLAM_E_CAPACITY, "state larger than max_landmarks");
+    if (L > 0 && !landmark_ids) return fail(c, ASLAM_E_INVALID, "landmark ids required");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<double> tmp((size_t)c->ekf.ld * c->ekf.ld, 0.0);
+    for (int col = 0; col < N; col++) std::memcpy(&tmp[(size_t)col * c->ekf.ld], sigma + (size_t)col * N, sizeof(double) * N);
+    HIP_TRY(c, hipMemcpy(c->ekf.d_sigma, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->ekf.d_mu, mu, sizeof(double) * N, hipMemcpyHostToDevice));
+    std::vector<int> id2idx(kIdTableSize, -1), idx2id(c->ekf.max_landmarks, -1);
+    for (int i = 0; i < L; i++) {
+        if (landmark_ids[i] < 0 || landmark_ids[i] >= kIdTableSize) return fail(c, ASLAM_E_INVALID, "landmark id out of range");
+        if (id2idx[landmark_ids[i]] < 0) id2idx[landmark_ids[i]] = i;
+        idx2id[i] = landmark_ids[i];
+    }
+    HIP_TRY(c, hipMemcpy(c->ekf.d_id2idx, id2idx.data(), sizeof(int) * kIdTableSize, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->ekf.d_idx2id, idx2id.data(), sizeof(int) * c->ekf.max_landmarks, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->ekf.d_L, &L, sizeof(int), hipMemcpyHostToDevice));
+    int zero = 0;
+    HIP_TRY(c, hipMemcpy(c->ekf.d_nlast, &zero, sizeof(int), hipMemcpyHostToDevice));
+    return ASLAM_OK;
+}
+
+int aslam_get_slot_detections(aslam_ctx* c, int slot, int* M, int* ids, float* corners, double* rvecs, double* tvecs) {
+    if (!c || !M) return fail(c, ASLAM_E_INVALID, "null argument");
+    int r = check_slot_range(c, slot, 1);
+    if (r) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->d_nmarkers + slot, sizeof(unsigned), hipMemcpyDeviceToHost));
+    n = std::min(n, (unsigned)kMarkerMax);
+    std::vector<Marker> h(n);
+    if (n) HIP_TRY(c, hipMemcpy(h.data(), c->d_markers + (size_t)slot * kMarkerMax, n * sizeof(Marker), hipMemcpyDeviceToHost));
+    *M = (int)n;
+    for (unsigned i = 0; i < n; i++) {
+        if (ids) ids[i] = h[i].id;
+        if (corners) std::memcpy(corners + 8 * i, h[i].c, sizeof(float) * 8);
+        if (rvecs) std::memcpy(rvecs + 3 * i, h[i].rvec, sizeof(double) * 3);
+        if (tvecs) std::memcpy(tvecs + 3 * i, h[i].tvec, sizeof(double) * 3);
+    }
+    return ASLAM_OK;
+}
+
+int aslam_get_detections(aslam_ctx* c, int* M, int* ids, float* corners, double* rvecs, double* tvecs) {
+    if (!c) return ASLAM_E_INVALID;
+    return aslam_get_slot_detections(c, c->last_first + std::max(c->last_count, 1) - 1, M, ids, corners, rvecs, tvecs);
+}
+
+int aslam_get_slot_raw_observations(aslam_ctx* c, int slot, int* n_out, int* ids, int* valid, double* xyth, double* Rdiag) {
+    if (!c || !n_out) return fail(c, ASLAM_E_INVALID, "null argument");
+    int r = check_slot_range(c, slot, 1);
+    if (r) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->d_nmarkers + slot, sizeof(unsigned), hipMemcpyDeviceToHost));
+    n = std::min(n, (unsigned)kMarkerMax);
+    std::vector<ObsRaw> h(n);
+    if (n) HIP_TRY(c, hipMemcpy(h.data(), c->d_obs + (size_t)slot * kMarkerMax, n * sizeof(ObsRaw), hipMemcpyDeviceToHost));
+    *n_out = (int)n;
+    for (unsigned i = 0; i < n; i++) {
+        if (ids) ids[i] = h[i].id;
+        if (valid) valid[i] = h[i].valid;
+        if (xyth) { xyth[3 * i] = h[i].x; xyth[3 * i + 1] = h[i].y; xyth[3 * i + 2] = h[i].th; }
+        if (Rdiag) std::memcpy(Rdiag + 3 * i, h[i].r, sizeof(double) * 3);
+    }
+    return ASLAM_OK;
+}
+
+int aslam_get_observations(aslam_ctx* c, int* n_out, int* ids, int* idx, int* action, double* xyth, double* Rdiag) {
+    if (!c || !n_out) return fail(c, ASLAM_E_INVALID, "null argument");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->ekf.d_npop, sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<PopRec> h(n);
+    if (n) HIP_TRY(c, hipMemcpy(h.data(), c->ekf.d_pop, n * sizeof(PopRec), hipMemcpyDeviceToHost));
+    *n_out = n;
+    for (int i = 0; i < n; i++) {
+        if (ids) ids[i] = h[i].id;
+        if (idx) idx[i] = h[i].index;
+        if (action) action[i] = h[i].action;
+        if (xyth) { xyth[3 * i] = h[i].z[0]; xyth[3 * i + 1] = h[i].z[1]; xyth[3 * i + 2] = h[i].z[2]; }
+        if (Rdiag) std::memcpy(Rdiag + 3 * i, h[i].r, sizeof(double) * 3);
+    }
+    return ASLAM_OK;
+}
+
+int aslam_get_landmark_ids(aslam_ctx* c, int* L, int* ids) {
+    if (!c || !L) return fail(c, ASLAM_E_INVALID, "null argument");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int n = 0;
+    HIP_TRY(c, hipMemcpy(&n, c->ekf.d_L, sizeof(int), hipMemcpyDeviceToHost));
+    *L = n;
+    if (ids && n) HIP_TRY(c, hipMemcpy(ids, c->ekf.d_idx2id, sizeof(int) * n, hipMemcpyDeviceToHost));
+    return ASLAM_OK;
+}
+
+int aslam_detect_batch(aslam_ctx* c, const uint8_t* frames, int nframes, int rows, int cols, int channels, size_t step,
+                       size_t frame_stride, int max_per_frame, int* counts, int* ids, float* corners, double* rvecs, double* tvecs) {
+    if (!c || !frames || !counts || nframes <= 0 || max_per_frame <= 0) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    for (int f0 = 0; f0 < nframes; f0 += c->max_batch) {
+        int nb = std::min(c->max_batch, nframes - f0);
+        int r = aslam_stage_frames(c, 0, frames + (size_t)f0 * frame_stride, nb, rows, cols, channels, step, frame_stride);
+        if (r) return r;
+        r = run_detect(c, 0, nb);
+        if (r) return r;
+        r = sync_and_check(c);
+        if (r) return r;
+        for (int i = 0; i < nb; i++) {
+            int M = 0;
+            std::vector<int> hid(kMarkerMax);
+            std::vector<float> hc((size_t)kMarkerMax * 8);
+            std::vector<double> hr((size_t)kMarkerMax * 3), ht((size_t)kMarkerMax * 3);
+            r = aslam_get_slot_detections(c, i, &M, hid.data(), hc.data(), hr.data(), ht.data());
+            if (r) return r;
+            const int f = f0 + i;
+            counts[f] = M;
+            const int m = std::min(M, max_per_frame);
+            if (ids) std::memcpy(ids + (size_t)f * max_per_frame, hid.data(), sizeof(int) * m);
+            if (corners) std::memcpy(corners + (size_t)f * max_per_frame * 8, hc.data(), sizeof(float) * 8 * m);
+            if (rvecs) std::memcpy(rvecs + (size_t)f * max_per_frame * 3, hr.data(), sizeof(double) * 3 * m);
+            if (tvecs) std::memcpy(tvecs + (size_t)f * max_per_frame * 3, ht.data(), sizeof(double) * 3 * m);
+        }
+    }
+    return ASLAM_OK;
+}
+
+int aslam_export_map(aslam_ctx* c, void* dst, int dst_is_device) {
+    if (!c || !dst) return fail(c, ASLAM_E_INVALID, "null argument");
+    launch_ekf_export_map(c->stream, c->ekf);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(dst, c->ekf.d_maprec, (size_t)ASLAM_MAP_RECORD_BYTES * c->ekf.max_landmarks,
+                              dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ASLAM_OK;
+}
+
+// ---- instrumentation -----------------------------------------------------------------------------------
+int aslam_debug_get_nbr(aslam_ctx* c, int slot, int scale, uint8_t* out) {
+    if (!c || !out || scale < 0 || scale >= kScales) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    int r = check_slot_range(c, slot, 1);
+    if (r) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const DetectCfg& g = c->cfg;
+    const uint8_t* src = c->d_nbr + (((size_t)slot * kScales + scale) * g.rows) * g.pitch;
+    HIP_TRY(c, hipMemcpy2DAsync(out, g.cols, src, g.pitch, g.cols, g.rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return ASLAM_OK;
+}
+
+// contours of one (slot, scale) of the LAST aslam_run_staged call, sorted into OpenCV order (descending key)
+int aslam_debug_get_contours(aslam_ctx* c, int slot, int scale, int max_contours, long long max_points, int* n_contours,
+                             int* sizes, int* keys, int* points_xy, long long* n_points) {
+    if (!c || !n_contours) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Counters h{};
+    HIP_TRY(c, hipMemcpy(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
+    unsigned nc = std::min(h.n_contours, c->cfg.cap_contours);
+    std::vector<ContourRec> recs(nc);
+    if (nc) HIP_TRY(c, hipMemcpy(recs.data(), c->d_contours, nc * sizeof(ContourRec), hipMemcpyDeviceToHost));
+    std::vector<ContourRec> sel;
+    const unsigned frame_rel = (unsigned)(slot - c->last_first);
+    for (auto& r : recs) if (r.frame == frame_rel && r.scale == (unsigned)scale) sel.push_back(r);
+    std::sort(sel.begin(), sel.end(), [](const ContourRec& a, const ContourRec& b) { return a.key > b.key; });
+    long long tot = 0;
+    int n = 0;
+    std::vector<unsigned> pts;
+    for (auto& r : sel) {
+        if (n >= max_contours || tot + (long long)r.n > max_points) return fail(c, ASLAM_E_CAPACITY, "debug buffer too small");
+        pts.resize(r.n);
+        if (r.n) HIP_TRY(c, hipMemcpy(pts.data(), c->d_points + r.off, r.n * sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (sizes) sizes[n] = (int)r.n;
+        if (keys) keys[n] = (int)r.key;
+        if (points_xy)
+            for (unsigned i = 0; i < r.n; i++) {
+                points_xy[2 * (tot + i)] = (int)(short)(pts[i] & 0xFFFFu);
+                points_xy[2 * (tot + i) + 1] = (int)(short)(pts[i] >> 16);
+            }
+        tot += r.n;
+        n++;
+    }
+    *n_contours = n;
+    if (n_points) *n_points = tot;
+    return ASLAM_OK;
+}
+
+int aslam_debug_get_candidates(aslam_ctx* c, int slot, int stage, int max, int* n_out, float* corners, int* sizes, int* ids) {
+    if (!c || !n_out) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    int r = check_slot_range(c, slot, 1);
+    if (r) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (stage == 0) {
+        unsigned n = 0;
+        HIP_TRY(c, hipMemcpy(&n, c->d_ncand + slot, sizeof(unsigned), hipMemcpyDeviceToHost));
+        n = std::min(n, (unsigned)kCandMax);
+        std::vector<CandRec> h(n);
+        if (n) HIP_TRY(c, hipMemcpy(h.data(), c->d_cands + (size_t)slot * kCandMax, n * sizeof(CandRec), hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end(), [](const CandRec& a, const CandRec& b) { return a.ordkey < b.ordkey; });
+        *n_out = (int)n;
+        for (unsigned i = 0; i < n && (int)i < max; i++) {
+            if (corners) for (int k = 0; k < 4; k++) { corners[8 * i + 2 * k] = h[i].x[k]; corners[8 * i + 2 * k + 1] = h[i].y[k]; }
+            if (sizes) sizes[i] = (int)h[i].n;
+            if (ids) ids[i] = -1;
+        }
+    } else {
+        unsigned n = 0;
+        HIP_TRY(c, hipMemcpy(&n, c->d_nfinal + slot, sizeof(unsigned), hipMemcpyDeviceToHost));
+        n = std::min(n, (unsigned)kCandMax);
+        std::vector<FinalCand> h(n);
+        if (n) HIP_TRY(c, hipMemcpy(h.data(), c->d_finals + (size_t)slot * kCandMax, n * sizeof(FinalCand), hipMemcpyDeviceToHost));
+        *n_out = (int)n;
+        for (unsigned i = 0; i < n && (int)i < max; i++) {
+            if (corners) std::memcpy(corners + 8 * i, h[i].c, sizeof(float) * 8);
+            if (sizes) sizes[i] = h[i].n;
+            if (ids) ids[i] = h[i].id;
+        }
+    }
+    return ASLAM_OK;
+}
+
+int aslam_profile_enable(aslam_ctx* c, int on) { if (!c) return ASLAM_E_INVALID; c->prof_on = on != 0; return ASLAM_OK; }
+int aslam_profile_reset(aslam_ctx* c) {
+    if (!c) return ASLAM_E_INVALID;
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (int i = 0; i < P_COUNT; i++) { c->prof_calls[i] = 0; c->prof_ms[i] = 0; }
+    return ASLAM_OK;
+}
+int aslam_profile_get(aslam_ctx* c, int max, const char** names, int* calls, double* total_ms) {
+    if (!c) return ASLAM_E_INVALID;
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    int n = std::min(max, (int)P_COUNT);
+    for (int i = 0; i < n; i++) {
+        if (names) names[i] = kProfNames[i];
+        if (calls) calls[i] = c->prof_calls[i];
+        if (total_ms) total_ms[i] = c->prof_ms[i];
+    }
+    return P_COUNT;
+}
+
+int aslam_synth_render(aslam_ctx* c, int slot, int rows, int cols, const double K[9], int n_markers, const int* ids,
+                       const double* poses, double marker_length, int background, int noise_amp, unsigned seed, int ss,
+                       uint8_t* out_host) {
+    if (!c || !K || n_markers < 0 || n_markers > 256 || (n_markers && (!ids || !poses)) || ss < 1 || ss > 8)
+        return fail(c, ASLAM_E_INVALID, "bad arguments");
+    int r = check_slot_range(c, slot, 1);
+    if (r) return r;
+    if (rows != c->rows || cols != c->cols || c->channels != 1) {
+        r = configure_frames(c, rows, cols, 1);
+        if (r) return r;
+    }
+    c->in_frame_bytes = (size_t)rows * cols;
+    const int nc = c->dict_ms + 2;
+    std::vector<SynthMarker> mk(n_markers);
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    for (int m = 0; m < n_markers; m++) {
+        if (ids[m] < 0 || ids[m] >= c->dict_n) return fail(c, ASLAM_E_INVALID, "marker id outside the dictionary");
+        const double* P = poses + 12 * m;      // R row-major then t
+        double H[9] = {P[0], P[1], P[9], P[3], P[4], P[10], P[6], P[7], P[11]};    // [r1 r2 t]
+        double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) + H[2] * (H[3] * H[7] - H[4] * H[6]);
+        if (det == 0) return fail(c, ASLAM_E_INVALID, "degenerate marker pose");
+        double d = 1.0 / det;
+        SynthMarker& S = mk[m];
+        S.Hinv[0] = (H[4] * H[8] - H[5] * H[7]) * d; S.Hinv[1] = (H[2] * H[7] - H[1] * H[8]) * d; S.Hinv[2] = (H[1] * H[5] - H[2] * H[4]) * d;
+        S.Hinv[3] = (H[5] * H[6] - H[3] * H[8]) * d; S.Hinv[4] = (H[0] * H[8] - H[2] * H[6]) * d; S.Hinv[5] = (H[2] * H[3] - H[0] * H[5]) * d;
+        S.Hinv[6] = (H[3] * H[7] - H[4] * H[6]) * d; S.Hinv[7] = (H[1] * H[6] - H[0] * H[7]) * d; S.Hinv[8] = (H[0] * H[4] - H[1] * H[3]) * d;
+        const double ext = marker_length * 0.5 + marker_length / nc;
+        double x0 = 1e30, y0 = 1e30, x1 = -1e30, y1 = -1e30;
+        for (int k = 0; k < 4; k++) {
+            double X = (k == 0 || k == 3) ? -ext : ext, Y = (k < 2) ? ext : -ext;
+            double px = H[0] * X + H[1] * Y + H[2], py = H[3] * X + H[4] * Y + H[5], pw = H[6] * X + H[7] * Y + H[8];
+            double u = fx * px / pw + cx, v = fy * py / pw + cy;
+            x0 = std::min(x0, u); x1 = std::max(x1, u); y0 = std::min(y0, v); y1 = std::max(y1, v);
+        }
+        S.bbox[0] = (int)std::floor(x0) - 2; S.bbox[1] = (int)std::floor(y0) - 2;
+        S.bbox[2] = (int)std::ceil(x1) + 2;  S.bbox[3] = (int)std::ceil(y1) + 2;
+        S.bits[0] = c->dict_cells[(size_t)ids[m] * 2];
+        S.bits[1] = c->dict_cells[(size_t)ids[m] * 2 + 1];
+    }
+    if (n_markers) HIP_TRY(c, hipMemcpyAsync(c->d_synth, mk.data(), mk.size() * sizeof(SynthMarker), hipMemcpyHostToDevice, c->stream));
+    uint8_t* dst = c->d_in + (size_t)slot * c->in_frame_bytes;
+    launch_render(c->stream, dst, rows, cols, fx, fy, cx, cy, n_markers, c->d_synth, nc, marker_length, background, noise_amp, seed, ss);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (out_host) HIP_TRY(c, hipMemcpy(out_host, dst, (size_t)rows * cols, hipMemcpyDeviceToHost));
+    return ASLAM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,101 @@
+// Shared host/device definitions for the MI355X (gfx950) ArUco EKF-SLAM hot path.
+// Replaces the role of OpenCV/Eigen in the reference's ArucoSlam (src/aruco_slam.cpp:21-74,
+// 76-263, 307-376); see DESIGN.md for the data layout in HBM and the kernel list.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+
+namespace aslam {
+
+constexpr int kScales = 3;        // adaptive-threshold windows 3, 13, 23 (DetectorParameters defaults)
+constexpr int kCandMax = 512;     // quad candidates kept per frame
+constexpr int kMarkerMax = 128;   // identified markers / observations per frame
+constexpr int kDictMaxCells = 9;  // markerSize + 2 border cells <= 9 (7x7 dictionaries)
+constexpr int kCellPx = 8;        // perspectiveRemovePixelPerCell (3.2.0 default)
+
+// overflow / error bits reported by the device in Counters::overflow
+enum : unsigned {
+    kOvfStarts = 1u, kOvfContours = 2u, kOvfPoints = 4u, kOvfCands = 8u, kOvfMarkers = 16u, kOvfLandmarks = 32u,
+};
+
+// Everything the detector kernels need to know about one batch (host-filled, passed by value).
+struct DetectCfg {
+    int rows, cols, pitch;            // pitch of the neighbour-mask planes (multiple of 64)
+    int win_r[kScales];               // box radius per scale: 1, 6, 11
+    int thresh_c;                     // floor(adaptiveThreshConstant) = 7
+    int min_perim, max_perim;         // contour point-count bounds
+    double approx_rate;               // polygonalApproxAccuracyRate (0.05)
+    double min_corner_rate;           // minCornerDistanceRate (0.05)
+    double min_marker_dist_rate;      // minMarkerDistanceRate (0.05)
+    int min_border_dist;              // minDistanceToBorder (3)
+    int marker_size;                  // dictionary markerSize (5)
+    int border_bits;                  // markerBorderBits (1)
+    int cell_margin;                  // int(0.13 * cellSize) = 1
+    int max_border_err;               // int(ms*ms*0.35)
+    int max_corr;                     // int(maxCorrectionBits * errorCorrectionRate)
+    int n_dict;                       // markers in the dictionary
+    double min_otsu_std;              // 5.0
+    unsigned cap_starts, cap_contours, cap_points;
+};
+
+struct Counters {
+    unsigned n_starts, q_trace, n_contours, q_quads, n_points, n_ident, q_ident, overflow;
+};
+
+struct ContourRec {
+    unsigned frame, scale, key, n, off;
+    short sx, sy;
+    int s0;
+};
+
+struct CandRec {                  // quad that passed _findMarkerContours
+    short x[4], y[4];
+    unsigned n;                   // contour point count ("perimeter" in 3.2.0)
+    unsigned ordkey;              // scale * 2^22 + (2^22 - 1 - key): ascending = OpenCV candidate order
+};
+
+struct FinalCand {                // candidate after _reorderCandidatesCorners + _filterTooCloseCandidates
+    float c[8];
+    int n;
+    int id;                       // >= 0 once identified, -1 rejected
+    int pad[2];
+};
+
+struct IdentWork { unsigned frame, idx; };
+
+struct Marker {                   // one detection: what detectMarkers + estimatePoseSingleMarkers return
+    int id;
+    int pad;
+    float c[8];
+    double rvec[3], tvec[3];
+};
+
+struct ObsRaw {                   // getObservations loop body, before landmark lookup (aruco_slam.cpp:325-369)
+    int id;
+    int valid;                    // 0 = dropped by the range / covariance gates
+    double x, y, th;
+    double r[3];                  // diagonal of observe_covariance_
+};
+
+struct CamParams {
+    double fx, fy, cx, cy;
+    double k[5];
+    int nD;
+    int pad;
+};
+
+struct SlamParams {
+    double Q_k, R_x, R_y, R_theta, kl, kr, b, marker_length;
+    double r2c_tx, r2c_ty;
+    float useful_distance_threshold;
+    int pad;
+};
+
+// start-list entry: x[0:12) y[12:24) scale[24:26) type[26] frame[32:48)
+__host__ __device__ inline unsigned long long pack_start(unsigned x, unsigned y, unsigned scale, unsigned type, unsigned frame) {
+    return (unsigned long long)x | ((unsigned long long)y << 12) | ((unsigned long long)scale << 24) |
+           ((unsigned long long)type << 26) | ((unsigned long long)frame << 32);
+}
+
+} // namespace aslam

@@ -1,0 +1,740 @@
+// Marker detection on gfx950: the device-side replacement for cv::aruco::detectMarkers as the reference
+// calls it (src/aruco_slam.cpp:313, default DetectorParameters).  Stages and what they replace:
+//
+//   k_threshold  BGR->gray + 3x adaptiveThreshold(MEAN_C, BINARY_INV, win 3/13/23, C=7) in ONE pass over the
+//                frame: LDS tile with a 12-px halo, LDS integral image, exact integer box means; emits, per
+//                scale, an 8-neighbour occupancy byte per pixel and the list of border start candidates.
+//   k_trace      Suzuki-Abe border following (findContours RETR_LIST/CHAIN_APPROX_NONE) without a sequential
+//                raster scan: every border is a cycle of (pixel, back-direction) states; a lane walks the cycle
+//                from each local start candidate and only the canonical one (the state the sequential scan would
+//                have started from) emits the contour.  Work-queue kernel, one lane per candidate.
+//   k_quads      approxPolyDP + the quad tests of _findMarkerContours, one lane per contour.
+//   k_assemble   candidate ordering (scale, reverse discovery), _reorderCandidatesCorners,
+//                _filterTooCloseCandidates; one workgroup per frame.
+//   k_identify   _extractBits (perspective warp, Otsu) + border check + Dictionary::identify; one wavefront
+//                per candidate.
+//
+// All integer / index results are bit-identical to the CPU oracle (oracle/detect.cpp); the fp64 sequences that
+// feed discrete decisions are written in the same operation order and the library is built with
+// -ffp-contract=off.
+#include "common.h"
+#include "detect.h"
+#include <cfloat>
+#include <climits>
+
+namespace aslam {
+
+// ------------------------------------------------------------------------------------------------
+// k_threshold
+// ------------------------------------------------------------------------------------------------
+constexpr int TW = 64, TH = 32, HALO = 12;
+constexpr int LW = TW + 2 * HALO;   // 88
+constexpr int LH = TH + 2 * HALO;   // 56
+
+__global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ in, int channels, size_t in_frame_stride,
+                                                   size_t in_row_step, uint8_t* __restrict__ gray_out,
+                                                   uint8_t* __restrict__ nbr, DetectCfg cfg,
+                                                   unsigned long long* __restrict__ starts, Counters* ctr) {
+    __shared__ uint8_t g[LH][LW];
+    __shared__ unsigned I[LH + 1][LW + 1];
+    __shared__ uint8_t bin[TH + 2][TW + 2];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int rows = cfg.rows, cols = cfg.cols;
+    const uint8_t* src = in + (size_t)b * in_frame_stride;
+
+    // 1. gray tile with replicated border (BORDER_REPLICATE of the box filter)
+    for (int i = tid; i < LH * LW; i += 256) {
+        int ly = i / LW, lx = i - ly * LW;
+        int gx = min(max(x0 + lx - HALO, 0), cols - 1);
+        int gy = min(max(y0 + ly - HALO, 0), rows - 1);
+        const uint8_t* p = src + (size_t)gy * in_row_step + (size_t)gx * channels;
+        unsigned v;
+        if (channels == 3) v = (p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14;
+        else v = p[0];
+        g[ly][lx] = (uint8_t)v;
+    }
+    __syncthreads();
+
+    // tight gray plane for the bit-extraction stage
+    for (int i = tid; i < TH * TW; i += 256) {
+        int ty = i / TW, tx = i - ty * TW;
+        int gx = x0 + tx, gy = y0 + ty;
+        if (gx < cols && gy < rows) gray_out[((size_t)b * rows + gy) * cols + gx] = g[ty + HALO][tx + HALO];
+    }
+
+    // 2. integral image I[y+1][x+1] = sum_{y'<=y, x'<=x} g
+    if (tid < LH) {
+        unsigned s = 0;
+        I[tid + 1][0] = 0;
+        for (int lx = 0; lx < LW; lx++) { s += g[tid][lx]; I[tid + 1][lx + 1] = s; }
+    }
+    if (tid >= 64 && tid < 64 + LW + 1) I[0][tid - 64] = 0;
+    __syncthreads();
+    if (tid < LW) {
+        unsigned s = 0;
+        for (int ly = 0; ly < LH; ly++) { s += I[ly + 1][tid + 1]; I[ly + 1][tid + 1] = s; }
+    }
+    __syncthreads();
+
+    // 3. three thresholds for the tile plus a 1-px ring (needed by the neighbour masks)
+    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
+        int by = i / (TW + 2), bx = i - by * (TW + 2);
+        int gx = x0 + bx - 1, gy = y0 + by - 1;
+        unsigned bits = 0;
+        if (gx >= 0 && gx < cols && gy >= 0 && gy < rows) {
+            int lx = bx - 1 + HALO, ly = by - 1 + HALO;
+            int v = g[ly][lx];
+#pragma unroll
+            for (int s = 0; s < kScales; s++) {
+                int r = cfg.win_r[s];
+                int k2 = (2 * r + 1) * (2 * r + 1);
+                unsigned sum = I[ly + r + 1][lx + r + 1] - I[ly - r][lx + r + 1] - I[ly + r + 1][lx - r] + I[ly - r][lx - r];
+                int mean = (int)((2u * sum + (unsigned)k2) / (2u * (unsigned)k2));   // round-to-nearest, never a tie
+                if (v - mean <= -cfg.thresh_c) bits |= 1u << s;
+            }
+        }
+        bin[by][bx] = (uint8_t)bits;
+    }
+    __syncthreads();
+
+    // 4. neighbour masks (bit d = neighbour in direction d is foreground; 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE)
+    //    and border start candidates
+    for (int u = tid; u < TH * TW / 4; u += 256) {
+        int ty = u / (TW / 4), tx4 = (u - ty * (TW / 4)) * 4;
+        int gy = y0 + ty;
+        unsigned out[kScales] = {0, 0, 0};
+        for (int j = 0; j < 4; j++) {
+            int tx = tx4 + j, gx = x0 + tx;
+            if (gx < cols && gy < rows) {
+                unsigned c = bin[ty + 1][tx + 1];
+                unsigned e = bin[ty + 1][tx + 2], ne = bin[ty][tx + 2], n = bin[ty][tx + 1], nw = bin[ty][tx];
+                unsigned w = bin[ty + 1][tx], sw = bin[ty + 2][tx], so = bin[ty + 2][tx + 1], se = bin[ty + 2][tx + 2];
+#pragma unroll
+                for (int s = 0; s < kScales; s++) {
+                    unsigned m = ((e >> s) & 1u) | (((ne >> s) & 1u) << 1) | (((n >> s) & 1u) << 2) | (((nw >> s) & 1u) << 3) |
+                                 (((w >> s) & 1u) << 4) | (((sw >> s) & 1u) << 5) | (((so >> s) & 1u) << 6) | (((se >> s) & 1u) << 7);
+                    unsigned fg = (c >> s) & 1u;
+                    out[s] |= m << (8 * j);
+                    // outer-type: foreground, W/NW/N/NE background, not isolated
+                    // hole-type : background, W and N foreground
+                    bool outer = fg && m != 0 && (m & 0x1Eu) == 0;
+                    bool hole = !fg && (m & 0x14u) == 0x14u;
+                    if (outer || hole) {
+                        unsigned k = atomicAdd(&ctr->n_starts, 1u);
+                        if (k < cfg.cap_starts) starts[k] = pack_start((unsigned)gx, (unsigned)gy, (unsigned)s, hole ? 1u : 0u, (unsigned)b);
+                        else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
+                    }
+                }
+            }
+        }
+        if (gy < rows) {
+#pragma unroll
+            for (int s = 0; s < kScales; s++) {
+                unsigned* dst = reinterpret_cast<unsigned*>(nbr + (((size_t)b * kScales + s) * rows + gy) * cfg.pitch + x0 + tx4);
+                *dst = out[s];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_trace
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dir_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }   // {1,1,0,-1,-1,-1,0,1}+1 packed
+__device__ __forceinline__ int dir_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }   // {0,-1,-1,-1,0,1,1,1}+1 packed
+// first foreground neighbour clockwise from W for a pixel whose NE,N,NW,W are background: E, SE, S, SW
+__device__ __forceinline__ int first_outer(unsigned m) { return (m & 1u) ? 0 : (m & 128u) ? 7 : (m & 64u) ? 6 : 5; }
+// first foreground neighbour clockwise from E: SE, S, SW, W, NW, N, NE = highest set bit among bits 7..1
+__device__ __forceinline__ int first_hole(unsigned m) { return 31 - __clz((int)(m & 0xFEu)); }
+
+struct Walk {
+    int x, y, s;
+};
+// one border-following step: first foreground neighbour counter-clockwise after the back direction
+__device__ __forceinline__ void walk_step(Walk& w, unsigned m) {
+    unsigned r = ((m | (m << 8)) >> (w.s + 1)) & 0xFFu;
+    int k = __ffs((int)r) - 1;
+    int s2 = (w.s + 1 + k) & 7;
+    w.x += dir_dx(s2);
+    w.y += dir_dy(s2);
+    w.s = (s2 + 4) & 7;
+}
+
+__global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, DetectCfg cfg,
+                                              const unsigned long long* __restrict__ starts, Counters* ctr,
+                                              ContourRec* __restrict__ contours, unsigned* __restrict__ points) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n_starts = min(ctr->n_starts, cfg.cap_starts);
+    const int pitch = cfg.pitch, cols = cfg.cols;
+    for (;;) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->q_trace, 64u);
+        base = __shfl(base, 0);
+        if (base >= n_starts) break;
+        unsigned idx = base + lane;
+        if (idx < n_starts) {
+            unsigned long long e = starts[idx];
+            int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
+            unsigned sc = (unsigned)((e >> 24) & 3u), type = (unsigned)((e >> 26) & 1u), f = (unsigned)(e >> 32);
+            const uint8_t* plane = nbr + ((size_t)f * kScales + sc) * cfg.rows * pitch;
+            const int key0 = y * cols + x;
+            if (type) x -= 1;                                  // hole border starts on the pixel left of the hole
+            unsigned m0 = plane[(size_t)y * pitch + x];
+            const int s0 = type ? first_hole(m0) : first_outer(m0);
+            const int sx = x, sy = y;
+
+            Walk w{sx, sy, s0};
+            long long area = 0;
+            int n = 0;
+            bool alive = true;
+            for (;;) {
+                unsigned m = plane[(size_t)w.y * pitch + w.x];
+                // is this state the start state of another scan candidate of my type with a smaller key?
+                if (type == 0) {
+                    if ((m & 0x1Eu) == 0 && w.s == first_outer(m) && w.y * cols + w.x < key0) { alive = false; break; }
+                } else {
+                    if ((m & 3u) == 2u && w.s == first_hole(m) && w.y * cols + w.x + 1 < key0) { alive = false; break; }
+                }
+                int px = w.x, py = w.y;
+                walk_step(w, m);
+                area += (long long)px * w.y - (long long)w.x * py;
+                n++;
+                if (w.x == sx && w.y == sy && w.s == s0) break;
+                if (n > cfg.max_perim) { alive = false; break; }
+            }
+            if (alive) {
+                bool is_hole = area > 0;                         // outer borders run counter-clockwise on screen
+                if ((unsigned)is_hole != type) alive = false;
+                if (n < cfg.min_perim || n > cfg.max_perim) alive = false;
+            }
+            if (alive) {
+                unsigned ci = atomicAdd(&ctr->n_contours, 1u);
+                unsigned off = atomicAdd(&ctr->n_points, (unsigned)n);
+                if (ci >= cfg.cap_contours) atomicOr(&ctr->overflow, (unsigned)kOvfContours);
+                else if ((unsigned long long)off + (unsigned)n > cfg.cap_points) {
+                    atomicOr(&ctr->overflow, (unsigned)kOvfPoints);
+                    ContourRec rec{f, sc, (unsigned)key0, 0u, 0u, (short)sx, (short)sy, s0};
+                    contours[ci] = rec;
+                } else {
+                    ContourRec rec{f, sc, (unsigned)key0, (unsigned)n, off, (short)sx, (short)sy, s0};
+                    contours[ci] = rec;
+                    Walk v{sx, sy, s0};
+                    for (int i = 0; i < n; i++) {
+                        points[off + i] = ((unsigned)v.x & 0xFFFFu) | ((unsigned)v.y << 16);
+                        unsigned m = plane[(size_t)v.y * pitch + v.x];
+                        walk_step(v, m);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_quads : approxPolyDP (closed) + quad tests, one lane per contour
+// ------------------------------------------------------------------------------------------------
+struct IPt { int x, y; };
+__device__ __forceinline__ IPt ld_pt(const unsigned* p, int i) {
+    unsigned v = p[i];
+    return IPt{(int)(short)(v & 0xFFFFu), (int)(short)(v >> 16)};
+}
+
+// Returns the number of vertices (<= 8) written to out, or -1 when the result cannot have 4 vertices.
+// Early exit rule: every stack slice yields at least one vertex and the final clean-up removes at most
+// floor(count/2) of them, so new_count + stack > 8 can never end at 4.
+__device__ int approx_poly_closed(const unsigned* __restrict__ src, int count, double eps, IPt* out) {
+    struct Range { int start, end; };
+    Range stack[10];
+    int top = 0;
+    IPt dst[9];
+    Range slice{0, 0}, right_slice{0, 0};
+    IPt start_pt{-1000000, -1000000}, end_pt{0, 0}, pt{0, 0};
+    int pos = 0, new_count = 0;
+    bool le_eps = false;
+    eps *= eps;
+
+    right_slice.start = 0;
+    for (int it = 0; it < 3; it++) {
+        double max_dist = 0;
+        pos = (pos + right_slice.start) % count;
+        start_pt = ld_pt(src, pos);
+        if (++pos >= count) pos = 0;
+        for (int j = 1; j < count; j++) {
+            pt = ld_pt(src, pos);
+            if (++pos >= count) pos = 0;
+            double dx = pt.x - start_pt.x, dy = pt.y - start_pt.y;
+            double dist = dx * dx + dy * dy;
+            if (dist > max_dist) { max_dist = dist; right_slice.start = j; }
+        }
+        le_eps = max_dist <= eps;
+    }
+    if (!le_eps) {
+        right_slice.end = slice.start = pos % count;
+        slice.end = right_slice.start = (right_slice.start + slice.start) % count;
+        stack[top++] = right_slice;
+        stack[top++] = slice;
+    } else {
+        dst[new_count++] = start_pt;
+    }
+    while (top > 0) {
+        slice = stack[--top];
+        end_pt = ld_pt(src, slice.end);
+        pos = slice.start;
+        start_pt = ld_pt(src, pos);
+        if (++pos >= count) pos = 0;
+        if (pos != slice.end) {
+            double max_dist = 0;
+            double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+            while (pos != slice.end) {
+                pt = ld_pt(src, pos);
+                if (++pos >= count) pos = 0;
+                double dist = fabs((pt.y - start_pt.y) * dx - (pt.x - start_pt.x) * dy);
+                if (dist > max_dist) { max_dist = dist; right_slice.start = (pos + count - 1) % count; }
+            }
+            le_eps = max_dist * max_dist <= eps * (dx * dx + dy * dy);
+        } else {
+            le_eps = true;
+            start_pt = ld_pt(src, slice.start);
+        }
+        if (le_eps) {
+            dst[new_count++] = start_pt;
+        } else {
+            right_slice.end = slice.end;
+            slice.end = right_slice.start;
+            stack[top++] = right_slice;
+            stack[top++] = slice;
+        }
+        if (new_count + top > 8) return -1;
+    }
+    // final clean-up
+    int count2 = new_count;
+    pos = count2 - 1;
+    start_pt = dst[pos]; if (++pos >= count2) pos = 0;
+    int wpos = pos;
+    pt = dst[pos]; if (++pos >= count2) pos = 0;
+    for (int i = 0; i < count2 && new_count > 2; i++) {
+        end_pt = dst[pos]; if (++pos >= count2) pos = 0;
+        double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
+        double dist = fabs((pt.x - start_pt.x) * dy - (pt.y - start_pt.y) * dx);
+        double sip = (double)(pt.x - start_pt.x) * (end_pt.x - pt.x) + (double)(pt.y - start_pt.y) * (end_pt.y - pt.y);
+        if (dist * dist <= 0.5 * eps * (dx * dx + dy * dy) && dx != 0 && dy != 0 && sip >= 0) {
+            new_count--;
+            dst[wpos] = start_pt = end_pt;
+            if (++wpos >= count2) wpos = 0;
+            pt = dst[pos]; if (++pos >= count2) pos = 0;
+            i++;
+            continue;
+        }
+        dst[wpos] = start_pt = pt;
+        if (++wpos >= count2) wpos = 0;
+        pt = end_pt;
+    }
+    for (int i = 0; i < new_count; i++) out[i] = dst[i];
+    return new_count;
+}
+
+__device__ __forceinline__ bool quad_is_convex(const IPt* p) {
+    const int n = 4;
+    IPt prev_pt = p[2], cur_pt = p[3];
+    int dx0 = cur_pt.x - prev_pt.x, dy0 = cur_pt.y - prev_pt.y;
+    int orientation = 0;
+    for (int i = 0; i < n; i++) {
+        prev_pt = cur_pt;
+        cur_pt = p[i];
+        int dx = cur_pt.x - prev_pt.x, dy = cur_pt.y - prev_pt.y;
+        int dxdy0 = dx * dy0, dydx0 = dy * dx0;
+        orientation |= (dydx0 > dxdy0) ? 1 : ((dydx0 < dxdy0) ? 2 : 3);
+        if (orientation == 3) return false;
+        dx0 = dx;
+        dy0 = dy;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void k_quads(DetectCfg cfg, Counters* ctr, const ContourRec* __restrict__ contours,
+                                              const unsigned* __restrict__ points, CandRec* __restrict__ cands,
+                                              unsigned* __restrict__ n_cand) {
+    const int lane = threadIdx.x & 63;
+    const unsigned n_contours = min(ctr->n_contours, cfg.cap_contours);
+    for (;;) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&ctr->q_quads, 64u);
+        base = __shfl(base, 0);
+        if (base >= n_contours) break;
+        unsigned idx = base + lane;
+        if (idx < n_contours) {
+            ContourRec rec = contours[idx];
+            if (rec.n > 0) {
+                IPt q[8];
+                int nv = approx_poly_closed(points + rec.off, (int)rec.n, (double)rec.n * cfg.approx_rate, q);
+                bool ok = nv == 4 && quad_is_convex(q);
+                if (ok) {
+                    int mx = max(cfg.cols, cfg.rows);
+                    double minDistSq = (double)mx * mx;
+                    for (int j = 0; j < 4; j++) {
+                        double ddx = (double)(q[j].x - q[(j + 1) & 3].x), ddy = (double)(q[j].y - q[(j + 1) & 3].y);
+                        double d = ddx * ddx + ddy * ddy;
+                        minDistSq = fmin(minDistSq, d);
+                    }
+                    double minCornerDistancePixels = (double)rec.n * cfg.min_corner_rate;
+                    if (minDistSq < minCornerDistancePixels * minCornerDistancePixels) ok = false;
+                    for (int j = 0; j < 4; j++)
+                        if (q[j].x < cfg.min_border_dist || q[j].y < cfg.min_border_dist ||
+                            q[j].x > cfg.cols - 1 - cfg.min_border_dist || q[j].y > cfg.rows - 1 - cfg.min_border_dist)
+                            ok = false;
+                }
+                if (ok) {
+                    unsigned k = atomicAdd(&n_cand[rec.frame], 1u);
+                    if (k < (unsigned)kCandMax) {
+                        CandRec c;
+                        for (int j = 0; j < 4; j++) { c.x[j] = (short)q[j].x; c.y[j] = (short)q[j].y; }
+                        c.n = rec.n;
+                        c.ordkey = rec.scale * (1u << 22) + ((1u << 22) - 1u - rec.key);
+                        cands[(size_t)rec.frame * kCandMax + k] = c;
+                    } else {
+                        atomicOr(&ctr->overflow, (unsigned)kOvfCands);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_assemble : one workgroup per frame
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble(DetectCfg cfg, Counters* ctr, const CandRec* __restrict__ cands,
+                                                  const unsigned* __restrict__ n_cand, FinalCand* __restrict__ finals,
+                                                  unsigned* __restrict__ n_final, IdentWork* __restrict__ work) {
+    __shared__ CandRec sIn[kCandMax];
+    __shared__ CandRec sC[kCandMax];
+    __shared__ unsigned nearBits[kCandMax][kCandMax / 32];
+    __shared__ unsigned char removed[kCandMax];
+    __shared__ int outPos[kCandMax];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x;
+    const int C = (int)min(n_cand[f], (unsigned)kCandMax);
+
+    for (int i = tid; i < C; i += 256) sIn[i] = cands[(size_t)f * kCandMax + i];
+    for (int i = tid; i < kCandMax * (kCandMax / 32); i += 256) (&nearBits[0][0])[i] = 0u;
+    for (int i = tid; i < kCandMax; i += 256) removed[i] = 0;
+    __syncthreads();
+    // rank sort by ordkey (unique inside a frame): OpenCV order = scale ascending, reverse discovery
+    for (int i = tid; i < C; i += 256) {
+        unsigned k = sIn[i].ordkey;
+        int rank = 0;
+        for (int j = 0; j < C; j++) rank += sIn[j].ordkey < k;
+        CandRec c = sIn[i];
+        // _reorderCandidatesCorners
+        double dx1 = (double)c.x[1] - c.x[0], dy1 = (double)c.y[1] - c.y[0];
+        double dx2 = (double)c.x[2] - c.x[0], dy2 = (double)c.y[2] - c.y[0];
+        double cross = (dx1 * dy2) - (dy1 * dx2);
+        if (cross < 0.0) {
+            short tx = c.x[1], ty = c.y[1];
+            c.x[1] = c.x[3]; c.y[1] = c.y[3];
+            c.x[3] = tx; c.y[3] = ty;
+        }
+        sC[rank] = c;
+    }
+    __syncthreads();
+    // _filterTooCloseCandidates, part 1: near pairs (i < j)
+    for (int p = tid; p < C * C; p += 256) {
+        int i = p / C, j = p - i * C;
+        if (j > i) {
+            const CandRec& a = sC[i];
+            const CandRec& bq = sC[j];
+            int minimumPerimeter = (int)min(a.n, bq.n);
+            double minMarkerDistancePixels = (double)minimumPerimeter * cfg.min_marker_dist_rate;
+            double thr = minMarkerDistancePixels * minMarkerDistancePixels;
+            bool near = false;
+            for (int fc = 0; fc < 4 && !near; fc++) {
+                double distSq = 0;
+                for (int c = 0; c < 4; c++) {
+                    int modC = (c + fc) & 3;
+                    double ddx = (double)(a.x[modC] - bq.x[c]), ddy = (double)(a.y[modC] - bq.y[c]);
+                    distSq += ddx * ddx + ddy * ddy;
+                }
+                distSq /= 4.;
+                if (distSq < thr) near = true;
+            }
+            if (near) atomicOr(&nearBits[i][j >> 5], 1u << (j & 31));
+        }
+    }
+    __syncthreads();
+    // part 2: sequential marking in pair order (depends on earlier removals)
+    if (tid == 0) {
+        for (int i = 0; i < C; i++)
+            for (int wd = 0; wd < (C + 31) / 32; wd++) {
+                unsigned bits = nearBits[i][wd];
+                while (bits) {
+                    int j = wd * 32 + (__ffs((int)bits) - 1);
+                    bits &= bits - 1;
+                    if (removed[i] || removed[j]) continue;
+                    if (sC[i].n > sC[j].n) removed[j] = 1;
+                    else removed[i] = 1;
+                }
+            }
+        int k = 0;
+        for (int i = 0; i < C; i++) { outPos[i] = removed[i] ? -1 : k; k += removed[i] ? 0 : 1; }
+        n_final[f] = (unsigned)k;
+    }
+    __syncthreads();
+    for (int i = tid; i < C; i += 256) {
+        int k = outPos[i];
+        if (k >= 0) {
+            FinalCand fc;
+            for (int j = 0; j < 4; j++) { fc.c[2 * j] = (float)sC[i].x[j]; fc.c[2 * j + 1] = (float)sC[i].y[j]; }
+            fc.n = (int)sC[i].n;
+            fc.id = -1;
+            fc.pad[0] = fc.pad[1] = 0;
+            finals[(size_t)f * kCandMax + k] = fc;
+            unsigned wi = atomicAdd(&ctr->n_ident, 1u);
+            work[wi] = IdentWork{(unsigned)f, (unsigned)k};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_identify : one wavefront per candidate
+// ------------------------------------------------------------------------------------------------
+constexpr int kWarpMax = kDictMaxCells * kCellPx;   // 72
+
+__global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, const uint8_t* __restrict__ gray,
+                                                 FinalCand* __restrict__ finals, const IdentWork* __restrict__ work,
+                                                 const unsigned long long* __restrict__ dict_codes) {
+    __shared__ double sA[8][8];
+    __shared__ double sB[8];
+    __shared__ double sM[9];
+    __shared__ uint8_t img[kWarpMax * kWarpMax];
+    __shared__ int hist[256];
+    __shared__ int sDecision[2];        // [0]: 0 = otsu, 1 = all zero bits, 2 = all one bits ; [1]: otsu threshold
+    const int lane = threadIdx.x & 63;
+    const int rows = cfg.rows, cols = cfg.cols;
+    const int ms = cfg.marker_size, bb = cfg.border_bits;
+    const int nc = ms + 2 * bb;                 // cells per side
+    const int S = nc * kCellPx;                 // warped image side
+    const unsigned n_work = ctr->n_ident;
+
+    for (;;) {
+        unsigned wi = 0;
+        if (lane == 0) wi = atomicAdd(&ctr->q_ident, 1u);
+        wi = __shfl(wi, 0);
+        if (wi >= n_work) break;
+        const IdentWork wk = work[wi];
+        FinalCand* fc = &finals[(size_t)wk.frame * kCandMax + wk.idx];
+        const uint8_t* gimg = gray + (size_t)wk.frame * rows * cols;
+
+        for (int i = lane; i < 256; i += 64) hist[i] = 0;
+        if (lane == 0) {
+            // cv::getPerspectiveTransform(corners -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)); elimination with partial pivoting
+            const float dstx[4] = {0.f, (float)S - 1, (float)S - 1, 0.f};
+            const float dsty[4] = {0.f, 0.f, (float)S - 1, (float)S - 1};
+            for (int i = 0; i < 4; i++) {
+                float sx = fc->c[2 * i], sy = fc->c[2 * i + 1];
+                sA[i][0] = sA[i + 4][3] = sx;
+                sA[i][1] = sA[i + 4][4] = sy;
+                sA[i][2] = sA[i + 4][5] = 1;
+                sA[i][3] = sA[i][4] = sA[i][5] = sA[i + 4][0] = sA[i + 4][1] = sA[i + 4][2] = 0;
+                sA[i][6] = -(double)sx * dstx[i];
+                sA[i][7] = -(double)sy * dstx[i];
+                sA[i + 4][6] = -(double)sx * dsty[i];
+                sA[i + 4][7] = -(double)sy * dsty[i];
+                sB[i] = dstx[i];
+                sB[i + 4] = dsty[i];
+            }
+            for (int col = 0; col < 8; col++) {
+                int piv = col;
+                double best = fabs(sA[col][col]);
+                for (int r = col + 1; r < 8; r++)
+                    if (fabs(sA[r][col]) > best) { best = fabs(sA[r][col]); piv = r; }
+                if (piv != col) {
+                    for (int c = 0; c < 8; c++) { double t = sA[piv][c]; sA[piv][c] = sA[col][c]; sA[col][c] = t; }
+                    double t = sB[piv]; sB[piv] = sB[col]; sB[col] = t;
+                }
+                for (int r = col + 1; r < 8; r++) {
+                    double fct = sA[r][col] / sA[col][col];
+                    for (int c = col; c < 8; c++) sA[r][c] -= fct * sA[col][c];
+                    sB[r] -= fct * sB[col];
+                }
+            }
+            double x[8];
+            for (int i = 7; i >= 0; i--) {
+                double s = sB[i];
+                for (int c = i + 1; c < 8; c++) s -= sA[i][c] * x[c];
+                x[i] = s / sA[i][i];
+            }
+            // cv::invert (3x3 cofactor form) for warpPerspective without WARP_INVERSE_MAP
+            double m0 = x[0], m1 = x[1], m2 = x[2], m3 = x[3], m4 = x[4], m5 = x[5], m6 = x[6], m7 = x[7], m8 = 1.0;
+            double det = m0 * (m4 * m8 - m5 * m7) - m1 * (m3 * m8 - m5 * m6) + m2 * (m3 * m7 - m4 * m6);
+            if (det != 0.) {
+                double d = 1. / det;
+                sM[0] = (m4 * m8 - m5 * m7) * d;
+                sM[1] = (m2 * m7 - m1 * m8) * d;
+                sM[2] = (m1 * m5 - m2 * m4) * d;
+                sM[3] = (m5 * m6 - m3 * m8) * d;
+                sM[4] = (m0 * m8 - m2 * m6) * d;
+                sM[5] = (m2 * m3 - m0 * m5) * d;
+                sM[6] = (m3 * m7 - m4 * m6) * d;
+                sM[7] = (m1 * m6 - m0 * m7) * d;
+                sM[8] = (m0 * m4 - m1 * m3) * d;
+            } else {
+                for (int i = 0; i < 9; i++) sM[i] = 0;
+            }
+        }
+        __syncthreads();
+
+        // warpPerspective(INTER_NEAREST), histogram, inner-region moments
+        const int lo = kCellPx / 2, hi = S - kCellPx / 2;
+        long long sum = 0, sq = 0;
+        for (int p = lane; p < S * S; p += 64) {
+            int y = p / S, x = p - y * S;
+            double X0 = sM[1] * y + sM[2], Y0 = sM[4] * y + sM[5], W0 = sM[7] * y + sM[8];
+            double W = W0 + sM[6] * x;
+            W = W ? 1. / W : 0;
+            double fX = fmax((double)INT_MIN, fmin((double)INT_MAX, (X0 + sM[0] * x) * W));
+            double fY = fmax((double)INT_MIN, fmin((double)INT_MAX, (Y0 + sM[3] * x) * W));
+            long long X = (long long)rint(fX), Y = (long long)rint(fY);
+            int v = 0;
+            if (X >= 0 && X < cols && Y >= 0 && Y < rows) v = gimg[(size_t)Y * cols + X];
+            img[p] = (uint8_t)v;
+            atomicAdd(&hist[v], 1);
+            if (x >= lo && x < hi && y >= lo && y < hi) { sum += v; sq += v * v; }
+        }
+        for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); sq += __shfl_down(sq, o); }
+        __syncthreads();
+        if (lane == 0) {
+            const double scale = 1.0 / ((double)(hi - lo) * (hi - lo));
+            const double mean = sum * scale;
+            const double var = fmax(sq * scale - mean * mean, 0.);
+            const double stddev = sqrt(var);
+            if (stddev < cfg.min_otsu_std) {
+                sDecision[0] = mean > 127 ? 2 : 1;
+                sDecision[1] = 0;
+            } else {
+                // getThreshVal_Otsu_8u over the whole warped image
+                const int N = S * S;
+                double mu = 0, sc = 1. / N;
+                for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
+                mu *= sc;
+                double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
+                for (int i = 0; i < 256; i++) {
+                    double p_i = hist[i] * sc;
+                    mu1 *= q1;
+                    q1 += p_i;
+                    double q2 = 1. - q1;
+                    if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
+                    mu1 = (mu1 + i * p_i) / q1;
+                    double mu2 = (mu - q1 * mu1) / q2;
+                    double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                    if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+                }
+                sDecision[0] = 0;
+                sDecision[1] = (int)max_val;
+            }
+        }
+        __syncthreads();
+        // cell votes: up to 81 cells, lanes take cells lane and lane + 64
+        unsigned long long bitsLo = 0, bitsHi = 0;       // cell index c -> bit c (lo) / c - 64 (hi)
+        {
+            const int dec = sDecision[0], T = sDecision[1];
+            const int wcell = kCellPx - 2 * cfg.cell_margin;
+            for (int half = 0; half < 2; half++) {
+                int c = lane + 64 * half;
+                int bit = 0;
+                if (c < nc * nc) {
+                    if (dec == 2) bit = 1;
+                    else if (dec == 0) {
+                        int cy = c / nc, cx = c - cy * nc;
+                        int Xs = cx * kCellPx + cfg.cell_margin, Ys = cy * kCellPx + cfg.cell_margin;
+                        int nz = 0;
+                        for (int yy = 0; yy < wcell; yy++)
+                            for (int xx = 0; xx < wcell; xx++) nz += img[(Ys + yy) * S + Xs + xx] > T;
+                        bit = nz > (wcell * wcell) / 2;
+                    }
+                }
+                unsigned long long bm = __ballot(bit);
+                if (half == 0) bitsLo = bm; else bitsHi = bm;
+            }
+        }
+        auto cell = [&](int cy, int cx) -> int {
+            int c = cy * nc + cx;
+            return c < 64 ? (int)((bitsLo >> c) & 1ull) : (int)((bitsHi >> (c - 64)) & 1ull);
+        };
+        // _getBorderErrors
+        int borderErr = 0;
+        for (int y = 0; y < nc; y++)
+            for (int k = 0; k < bb; k++) { borderErr += cell(y, k); borderErr += cell(y, nc - 1 - k); }
+        for (int x = bb; x < nc - bb; x++)
+            for (int k = 0; k < bb; k++) { borderErr += cell(k, x); borderErr += cell(nc - 1 - k, x); }
+        int id = -1, rot = 0;
+        if (borderErr <= cfg.max_border_err) {
+            // inner bits, row-major MSB first (rotation 0 of Dictionary::getByteListFromBits)
+            unsigned long long code = 0;
+            for (int r = 0; r < ms; r++)
+                for (int c = 0; c < ms; c++) code = (code << 1) | (unsigned long long)cell(r + bb, c + bb);
+            // Dictionary::identify: first marker whose best rotation is within the correction budget
+            int bestM = INT_MAX, bestR = 0;
+            for (int m = lane; m < cfg.n_dict; m += 64) {
+                int minD = ms * ms + 1, minR = -1;
+                for (int r = 0; r < 4; r++) {
+                    int h = __popcll(dict_codes[(size_t)m * 4 + r] ^ code);
+                    if (h < minD) { minD = h; minR = r; }
+                }
+                if (minD <= cfg.max_corr && m < bestM) { bestM = m; bestR = minR; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                int om = __shfl_down(bestM, o), orr = __shfl_down(bestR, o);
+                if (om < bestM) { bestM = om; bestR = orr; }
+            }
+            bestM = __shfl(bestM, 0);
+            bestR = __shfl(bestR, 0);
+            if (bestM != INT_MAX) { id = bestM; rot = bestR; }
+        } else {
+            // keep the wave convergent: the shuffles above are executed by all lanes or by none
+        }
+        if (lane == 0) {
+            if (id >= 0 && rot != 0) {
+                // std::rotate(begin, begin + 4 - rot, end): new[j] = old[(j + 4 - rot) % 4]
+                float o[8];
+                for (int i = 0; i < 8; i++) o[i] = fc->c[i];
+                for (int j = 0; j < 4; j++) {
+                    int sidx = (j + 4 - rot) & 3;
+                    fc->c[2 * j] = o[2 * sidx];
+                    fc->c[2 * j + 1] = o[2 * sidx + 1];
+                }
+            }
+            fc->id = id;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t frame_stride, size_t row_step, int nframes,
+                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned long long* starts, Counters* ctr) {
+    dim3 grid((cfg.cols + TW - 1) / TW, (cfg.rows + TH - 1) / TH, nframes);
+    hipLaunchKernelGGL(k_threshold, grid, dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg, starts, ctr);
+}
+void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, const unsigned long long* starts,
+                  Counters* ctr, ContourRec* contours, unsigned* points) {
+    hipLaunchKernelGGL(k_trace, dim3(nwaves), dim3(64), 0, st, nbr, cfg, starts, ctr, contours, points);
+}
+void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, Counters* ctr, const ContourRec* contours,
+                  const unsigned* points, CandRec* cands, unsigned* n_cand) {
+    hipLaunchKernelGGL(k_quads, dim3(nwaves), dim3(64), 0, st, cfg, ctr, contours, points, cands, n_cand);
+}
+void launch_assemble(hipStream_t st, int nframes, const DetectCfg& cfg, Counters* ctr, const CandRec* cands,
+                     const unsigned* n_cand, FinalCand* finals, unsigned* n_final, IdentWork* work) {
+    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), 0, st, cfg, ctr, cands, n_cand, finals, n_final, work);
+}
+void launch_identify(hipStream_t st, int nwaves, const DetectCfg& cfg, Counters* ctr, const uint8_t* gray,
+                     FinalCand* finals, const IdentWork* work, const unsigned long long* dict_codes) {
+    hipLaunchKernelGGL(k_identify, dim3(nwaves), dim3(64), 0, st, cfg, ctr, gray, finals, work, dict_codes);
+}
+
+} // namespace aslam

@@ -1,0 +1,60 @@
+// EKF-SLAM state resident in HBM and the launchers of the EKF kernels (ekf.hip).
+// Replaces Eigen's role in ArucoSlam::addEncoder / addImage (src/aruco_slam.cpp:21-74, 88-263).
+#pragma once
+#include "common.h"
+
+namespace aslam {
+
+constexpr int kIdTableSize = 1024;     // marker id -> landmark index (std::map<int,int> aruco_id_map, aruco_slam.h:164)
+
+struct PopRec {                        // one popped observation (aruco_slam.cpp:92-95) and what was done with it
+    int id, index, action, pad;        // action: 0 augment, 1 update, 2 stationary no-op
+    double z[3];
+    double r[3];
+};
+struct LastObs {                       // last_observed_marker_ entry (aruco_slam.h:188): id + last_observation_
+    int id, pad;
+    double z[3];                       // NaN = never set (quirk Q2/Q3: never matches)
+};
+struct UpdRec {                        // one fused EKF correction
+    int li, pad;                       // state offset of the landmark: 3 + 3*index
+    double Gxm[18];                    // 3 x 6 Jacobian block (aruco_slam.cpp:140-143)
+    double ze[3];                      // innovation (aruco_slam.cpp:137-138)
+    double r[3];                       // diag of Rk
+};
+struct MapRecord {                     // 104-byte landmark record gathered across GPUs
+    int id, index;
+    double x, y, theta;
+    double S[9];
+};
+
+struct EkfState {
+    int max_landmarks, ld;             // ld = 3 + 3*max_landmarks: leading dimension of sigma (column-major)
+    double* d_mu;
+    double* d_sigma;
+    int* d_L;                          // landmarks in the map (N = 3 + 3 L)
+    int* d_id2idx;
+    int* d_idx2id;
+    LastObs* d_last;
+    int* d_nlast;
+    PopRec* d_pop;
+    int* d_npop;
+    UpdRec* d_upd;
+    int* d_m;                          // fused updates this frame
+    double *d_V, *d_Wt, *d_T;          // 3m x ld each, row k contiguous
+    double *d_Sv, *d_Sw, *d_alpha, *d_gamma, *d_G, *d_g;
+    MapRecord* d_maprec;
+};
+
+hipError_t ekf_alloc(EkfState& E, int max_landmarks);
+void ekf_free(EkfState& E);
+void launch_ekf_predict_only(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt);
+void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int do_predict,
+                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr);
+void launch_ekf_gather(hipStream_t st, const EkfState& E);
+void launch_ekf_small(hipStream_t st, const EkfState& E);
+void launch_ekf_T(hipStream_t st, const EkfState& E);
+void launch_ekf_update(hipStream_t st, const EkfState& E);
+void launch_ekf_export_map(hipStream_t st, const EkfState& E);
+
+} // namespace aslam

@@ -1,0 +1,598 @@
+// SE(2) EKF-SLAM on gfx950, state resident in HBM (mu: N doubles, Sigma: N x N doubles column-major with a
+// fixed leading dimension so the map grows in place).  Replaces the Eigen arithmetic of
+//   ArucoSlam::addEncoder  (src/aruco_slam.cpp:21-74)    -> predict part of k_ekf_plan / k_ekf_predict
+//   ArucoSlam::addImage    (src/aruco_slam.cpp:88-263)   -> k_ekf_plan (queue order, augment, update plan)
+//                                                           + k_ekf_gather / k_ekf_small / k_ekf_T / k_ekf_update
+// The reference applies the M updates of a frame one after another with dense N x N x N products.  Every
+// update is linearised at the same frozen pre-frame mean (aruco_slam.cpp:88), so the M sequential rank-3
+// corrections compose EXACTLY into one rank-3M correction
+//     Sigma <- Sigma0 - W G V ,   mu <- mu + W g ,
+// with V = H Sigma0 (3M x N, from rows), W = Sigma0 H^T (N x 3M, from columns) and small 3M x 3M factors G, g
+// obtained by replaying the sequential recurrences on 3x3 blocks (k_ekf_small).  Sigma is then streamed once
+// per frame (k_ekf_update) instead of 2M times.  Observations that take the reference's "stationary" no-op
+// branch (aruco_slam.cpp:192-198) are excluded; new landmarks are appended first (they pop first).
+#include "common.h"
+#include "ekf.h"
+#include <cmath>
+
+namespace aslam {
+
+__device__ __forceinline__ void wrap1(double& a) {      // ArucoSlam::normAngle (aruco_slam.cpp:412-421): wraps once
+    const double PI = 3.14159265358979323846;
+    if (a >= PI) a -= 2.0 * PI;
+    if (a < -PI) a += 2.0 * PI;
+}
+
+__device__ void inv3_pp(const double* A, double* out) {   // 3x3 inverse by partial-pivot LU (Eigen dynamic .inverse())
+    double a[3][6];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { a[i][j] = A[i * 3 + j]; a[i][3 + j] = (i == j) ? 1. : 0.; }
+    for (int col = 0; col < 3; col++) {
+        int piv = col;
+        double best = fabs(a[col][col]);
+        for (int r = col + 1; r < 3; r++)
+            if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
+        if (piv != col)
+            for (int c = 0; c < 6; c++) { double t = a[piv][c]; a[piv][c] = a[col][c]; a[col][c] = t; }
+        for (int r = col + 1; r < 3; r++) {
+            double f = a[r][col] / a[col][col];
+            for (int c = col; c < 6; c++) a[r][c] -= f * a[col][c];
+        }
+    }
+    for (int j = 0; j < 3; j++)
+        for (int i = 2; i >= 0; i--) {
+            double s = a[i][3 + j];
+            for (int c = i + 1; c < 3; c++) s -= a[i][c] * out[c * 3 + j];
+            out[i * 3 + j] = s / a[i][i];
+        }
+}
+
+// ---- predict (aruco_slam.cpp:35-73), executed by one workgroup -------------------------------------------
+// Sigma <- Hx Sigma Hx^T + F Qk F^T with Hx = identity except its 3x3 corner: rows 0..2 first, then columns 0..2.
+__device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int N,
+                              double* sH /*shared 9*/, double* sQ /*shared 9*/) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ld = E.ld;
+    if (tid == 0) {
+        double delta_enl = dt * wl, delta_enr = dt * wr;
+        double delta_sl = sp.kl * delta_enl, delta_sr = sp.kr * delta_enr;
+        double l_ = 2 * sp.b;
+        double delta_theta = (delta_sr - delta_sl) / l_;
+        double delta_s = 0.5 * (delta_sr + delta_sl);
+        double tmp_th = E.d_mu[2] + 0.5 * delta_theta;
+        double c = cos(tmp_th), s = sin(tmp_th);
+        E.d_mu[0] += delta_s * c;
+        E.d_mu[1] += delta_s * s;
+        double th = E.d_mu[2] + delta_theta;
+        wrap1(th);
+        E.d_mu[2] = th;
+        sH[0] = 1.0; sH[1] = 0.0; sH[2] = -delta_s * s;
+        sH[3] = 0.0; sH[4] = 1.0; sH[5] = delta_s * c;
+        sH[6] = 0.0; sH[7] = 0.0; sH[8] = 1.0;
+        const double f = 0.5 * sp.kl * dt;                       // kl for BOTH wheels (quirk Q7)
+        double wkh[6] = {f * c, f * c, f * s, f * s, f * (1 / sp.b), f * (-1 / sp.b)};
+        double su0 = sp.Q_k * fabs(wl), su1 = sp.Q_k * fabs(wr);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) sQ[i * 3 + j] = wkh[i * 2] * su0 * wkh[j * 2] + wkh[i * 2 + 1] * su1 * wkh[j * 2 + 1];
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += nt) {
+        double* col = E.d_sigma + (size_t)j * ld;
+        double a = col[0], b = col[1], c = col[2];
+        col[0] = sH[0] * a + sH[1] * b + sH[2] * c;
+        col[1] = sH[3] * a + sH[4] * b + sH[5] * c;
+        col[2] = sH[6] * a + sH[7] * b + sH[8] * c;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += nt) {
+        double a = E.d_sigma[i], b = E.d_sigma[(size_t)ld + i], c = E.d_sigma[(size_t)2 * ld + i];
+        E.d_sigma[i] = a * sH[0] + b * sH[1] + c * sH[2];
+        E.d_sigma[(size_t)ld + i] = a * sH[3] + b * sH[4] + c * sH[5];
+        E.d_sigma[(size_t)2 * ld + i] = a * sH[6] + b * sH[7] + c * sH[8];
+    }
+    __syncthreads();
+    if (tid < 9) {
+        int i = tid / 3, j = tid - 3 * i;
+        E.d_sigma[(size_t)j * ld + i] += sQ[i * 3 + j];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_ekf_predict(EkfState E, SlamParams sp, double wl, double wr, double dt) {
+    __shared__ double sH[9], sQ[9];
+    const int N = 3 + 3 * (*E.d_L);
+    predict_block(E, sp, wl, wr, dt, N, sH, sQ);
+}
+
+// ---- plan: predict + queue order + augment + update plan (one workgroup) -----------------------------------
+__global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, double wl, double wr, double dt, int do_predict,
+                                                  const ObsRaw* __restrict__ obs, const unsigned* __restrict__ n_markers,
+                                                  Counters* ctr) {
+    __shared__ double sH[9], sQ[9];
+    __shared__ int sHeap[kMarkerMax];          // heap of observation slots
+    __shared__ int sIndex[kMarkerMax];         // aruco_index_ per slot
+    __shared__ int sOrder[kMarkerMax];         // pop order
+    __shared__ int sNPop, sL, sM;
+    __shared__ double sG[9], sMM[9], sNew[3];
+    __shared__ int sDoAug;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ld = E.ld;
+
+    int L = *E.d_L;
+    if (do_predict) predict_block(E, sp, wl, wr, dt, 3 + 3 * L, sH, sQ);
+
+    const int nM = (int)min(*n_markers, (unsigned)kMarkerMax);
+    const double mu0x = E.d_mu[0], mu0y = E.d_mu[1], mu0t = E.d_mu[2];     // frozen pre-frame robot pose (Q1)
+
+    if (tid == 0) {
+        // obs_.push(ob) in detection order (aruco_slam.cpp:369-373): libstdc++ std::priority_queue = push_heap
+        // with operator< inverted on aruco_index_ (aruco_slam.h:85-88): new markers (-1) first, then ascending index
+        int len = 0;
+        for (int i = 0; i < nM; i++) {
+            if (!obs[i].valid) continue;
+            int id = obs[i].id;
+            int index = (id >= 0 && id < kIdTableSize) ? E.d_id2idx[id] : -1;      // checkLandmark (aruco_slam.cpp:423-435)
+            sIndex[i] = index;
+            int hole = len++, value = i;
+            int parent = (hole - 1) / 2;
+            while (hole > 0 && sIndex[sHeap[parent]] > sIndex[value]) {            // comp(parent, value) = parent < value
+                sHeap[hole] = sHeap[parent];
+                hole = parent;
+                parent = (hole - 1) / 2;
+            }
+            sHeap[hole] = value;
+        }
+        int np = 0;
+        while (len > 0) {
+            sOrder[np++] = sHeap[0];                                               // top()
+            if (len > 1) {                                                         // pop_heap -> __adjust_heap
+                int value = sHeap[len - 1];
+                sHeap[len - 1] = sHeap[0];
+                int n = len - 1, hole = 0, second = 0;
+                while (second < (n - 1) / 2) {
+                    second = 2 * (second + 1);
+                    if (sIndex[sHeap[second]] > sIndex[sHeap[second - 1]]) second--;
+                    sHeap[hole] = sHeap[second];
+                    hole = second;
+                }
+                if ((n & 1) == 0 && second == (n - 2) / 2) {
+                    second = 2 * (second + 1);
+                    sHeap[hole] = sHeap[second - 1];
+                    hole = second - 1;
+                }
+                int parent = (hole - 1) / 2;
+                while (hole > 0 && sIndex[sHeap[parent]] > sIndex[value]) {
+                    sHeap[hole] = sHeap[parent];
+                    hole = parent;
+                    parent = (hole - 1) / 2;
+                }
+                sHeap[hole] = value;
+            }
+            len--;
+        }
+        sNPop = np;
+        sL = L;
+        sM = 0;
+    }
+    __syncthreads();
+    const int np = sNPop;
+
+    for (int q = 0; q < np; q++) {
+        const int slot = sOrder[q];
+        const int index = sIndex[slot];
+        if (index < 0) {
+            // ---- new landmark (aruco_slam.cpp:208-260) ----
+            if (tid == 0) {
+                const ObsRaw o = obs[slot];
+                L = sL;
+                PopRec pr;
+                pr.id = o.id; pr.index = -1; pr.action = 0; pr.pad = 0;
+                pr.z[0] = o.x; pr.z[1] = o.y; pr.z[2] = o.th;
+                pr.r[0] = o.r[0]; pr.r[1] = o.r[1]; pr.r[2] = o.r[2];
+                E.d_pop[q] = pr;
+                if (L >= E.max_landmarks) {
+                    atomicOr(&ctr->overflow, (unsigned)kOvfLandmarks);
+                    sDoAug = 0;
+                } else {
+                    sDoAug = 1;
+                    float sinth = (float)sin(mu0t);                               // float trig (quirk Q4)
+                    float costh = (float)cos(mu0t);
+                    double map_x = mu0x + costh * o.x - sinth * o.y;
+                    double map_y = mu0y + sinth * o.x + costh * o.y;
+                    double map_theta = mu0t + o.th;
+                    wrap1(map_theta);
+                    sNew[0] = map_x; sNew[1] = map_y; sNew[2] = map_theta;
+                    double deltax = map_x - mu0x, deltay = map_y - mu0y;
+                    double Gsk[9] = {-costh, -sinth, -sinth * deltax + costh * deltay,
+                                     sinth, -costh, -deltax * costh - deltay * sinth,
+                                     0, 0, -1};
+                    double Gmi[9] = {costh, sinth, 0, -sinth, costh, 0, 0, 0, 1};
+                    double ss[9], T1[9], T2[9], T3[9];
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ss[i * 3 + j] = E.d_sigma[(size_t)j * ld + i];
+                    // sigma_mm = Gmi * (Gsk*sigma_s*Gsk^T + Rk)^T * Gmi^T   (quirk Q5, literal)
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                        double s = 0; for (int k = 0; k < 3; k++) s += Gsk[i * 3 + k] * ss[k * 3 + j]; T1[i * 3 + j] = s; }
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                        double s = 0; for (int k = 0; k < 3; k++) s += T1[i * 3 + k] * Gsk[j * 3 + k];
+                        T2[i * 3 + j] = s + (i == j ? o.r[i] : 0.0); }
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                        double s = 0; for (int k = 0; k < 3; k++) s += Gmi[i * 3 + k] * T2[j * 3 + k]; T3[i * 3 + j] = s; }
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                        double s = 0; for (int k = 0; k < 3; k++) s += T3[i * 3 + k] * Gmi[j * 3 + k]; sMM[i * 3 + j] = s; }
+                    // sigma_mx = (-Gmi * Gsk) * sigma_.topRows(3)
+                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                        double s = 0; for (int k = 0; k < 3; k++) s += (-Gmi[i * 3 + k]) * Gsk[k * 3 + j]; sG[i * 3 + j] = s; }
+                }
+            }
+            __syncthreads();
+            if (sDoAug) {
+                const int N = 3 + 3 * sL;
+                for (int c = tid; c < N; c += nt) {
+                    const double* col = E.d_sigma + (size_t)c * ld;
+                    double a = col[0], b = col[1], d = col[2];
+                    for (int i = 0; i < 3; i++) {
+                        double v = sG[i * 3] * a + sG[i * 3 + 1] * b + sG[i * 3 + 2] * d;
+                        E.d_sigma[(size_t)c * ld + N + i] = v;            // bottom-left block: sigma_mx
+                        E.d_sigma[(size_t)(N + i) * ld + c] = v;          // top-right block: sigma_mx^T
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    for (int i = 0; i < 3; i++)
+                        for (int j = 0; j < 3; j++) E.d_sigma[(size_t)(N + j) * ld + N + i] = sMM[i * 3 + j];
+                    E.d_mu[N] = sNew[0]; E.d_mu[N + 1] = sNew[1]; E.d_mu[N + 2] = sNew[2];
+                    const int id = obs[slot].id;
+                    if (id >= 0 && id < kIdTableSize && E.d_id2idx[id] < 0) E.d_id2idx[id] = sL;   // map::insert keeps the first (Q10)
+                    E.d_idx2id[sL] = id;
+                    sL = sL + 1;
+                }
+            }
+            __syncthreads();
+        } else {
+            // ---- already mapped (aruco_slam.cpp:108-207) ----
+            if (tid == 0) {
+                const ObsRaw o = obs[slot];
+                const int li = 3 + 3 * index;
+                double z[3] = {o.x, o.y, o.th};
+                // "stationary" test against the previous frame (aruco_slam.cpp:192-198): a no-op branch (quirk Q2)
+                bool stationary = false;
+                const int nl = *E.d_nlast;
+                for (int k = 0; k < nl; k++)
+                    if (E.d_last[k].id == o.id) {                                  // std::find: first with the same id
+                        double d0 = E.d_last[k].z[0] - z[0], d1 = E.d_last[k].z[1] - z[1], d2 = E.d_last[k].z[2] - z[2];
+                        stationary = sqrt(d0 * d0 + d1 * d1 + d2 * d2) < 0.01;     // NaN compares false (Q2/Q3)
+                        break;
+                    }
+                PopRec pr;
+                pr.id = o.id; pr.index = index; pr.action = stationary ? 2 : 1; pr.pad = 0;
+                pr.z[0] = z[0]; pr.z[1] = z[1]; pr.z[2] = z[2];
+                pr.r[0] = o.r[0]; pr.r[1] = o.r[1]; pr.r[2] = o.r[2];
+                E.d_pop[q] = pr;
+                if (!stationary) {
+                    double mx = E.d_mu[li], my = E.d_mu[li + 1], mth = E.d_mu[li + 2];   // unchanged since frame start
+                    double sintheta = sin(mu0t), costheta = cos(mu0t);
+                    double gdx = mx - mu0x, gdy = my - mu0y, gdth = mth - mu0t;
+                    wrap1(gdth);
+                    double zh0 = gdx * costheta + gdy * sintheta, zh1 = -gdx * sintheta + gdy * costheta;
+                    UpdRec u;
+                    u.li = li; u.pad = 0;
+                    u.ze[0] = z[0] - zh0; u.ze[1] = z[1] - zh1; u.ze[2] = z[2] - gdth;
+                    wrap1(u.ze[2]);
+                    const double G[18] = {-costheta, -sintheta, -gdx * sintheta + gdy * costheta, costheta, sintheta, 0,
+                                          sintheta, -costheta, -gdx * costheta - gdy * sintheta, -sintheta, costheta, 0,
+                                          0, 0, -1, 0, 0, 1};
+                    for (int k = 0; k < 18; k++) u.Gxm[k] = G[k];
+                    u.r[0] = o.r[0]; u.r[1] = o.r[1]; u.r[2] = o.r[2];
+                    E.d_upd[sM] = u;
+                    sM = sM + 1;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        // last_observed_marker_ = observed_marker (aruco_slam.cpp:263): last_observation_ is only ever set in the
+        // update branch (:202); everywhere else it stays unset -> NaN sentinel
+        const double qnan = nan("");
+        for (int q = 0; q < np; q++) {
+            LastObs lo;
+            lo.id = E.d_pop[q].id; lo.pad = 0;
+            if (E.d_pop[q].action == 1) { lo.z[0] = E.d_pop[q].z[0]; lo.z[1] = E.d_pop[q].z[1]; lo.z[2] = E.d_pop[q].z[2]; }
+            else { lo.z[0] = lo.z[1] = lo.z[2] = qnan; }
+            E.d_last[q] = lo;
+        }
+        *E.d_nlast = np;
+        *E.d_npop = np;
+        *E.d_L = sL;
+        *E.d_m = sM;
+    }
+}
+
+// ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns) -----------------------------------------------
+__global__ __launch_bounds__(256) void k_ekf_gather(EkfState E) {
+    const int m = *E.d_m;
+    const int N = 3 + 3 * (*E.d_L);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int ld = E.ld;
+    if (m > 0 && t < N) {
+        const double* col = E.d_sigma + (size_t)t * ld;           // column t: Sigma(:, t)
+        const double c0 = col[0], c1 = col[1], c2 = col[2];
+        const double r0 = E.d_sigma[t], r1 = E.d_sigma[(size_t)ld + t], r2 = E.d_sigma[(size_t)2 * ld + t];   // Sigma(t, 0..2)
+        for (int k = 0; k < m; k++) {
+            const UpdRec& u = E.d_upd[k];
+            const double l0 = col[u.li], l1 = col[u.li + 1], l2 = col[u.li + 2];
+            const double q0 = E.d_sigma[(size_t)u.li * ld + t], q1 = E.d_sigma[(size_t)(u.li + 1) * ld + t],
+                         q2 = E.d_sigma[(size_t)(u.li + 2) * ld + t];
+            for (int a = 0; a < 3; a++) {
+                const double* g = &u.Gxm[a * 6];
+                E.d_V[(size_t)(3 * k + a) * ld + t] = g[0] * c0 + g[1] * c1 + g[2] * c2 + g[3] * l0 + g[4] * l1 + g[5] * l2;
+                E.d_Wt[(size_t)(3 * k + a) * ld + t] = r0 * g[0] + r1 * g[1] + r2 * g[2] + q0 * g[3] + q1 * g[4] + q2 * g[5];
+            }
+        }
+    }
+}
+
+// ---- small: replay the sequential recurrences on 3x3 blocks -> G (3m x 3m), g (3m) -------------------------
+// With HP_i = sum_l alpha_il V_l and PH_i = sum_l W_l beta_li (alpha block lower-, beta block upper-triangular,
+// identity diagonals), S_i = HP_i H_i^T + R_i, K_i = PH_i S_i^-1:
+//   C_ji = HP_j H_i^T = sum_{l<=j} alpha_jl Sv_li        D_ij = H_i K_j = sum_{l<=j} Sw_il gamma_lj
+//   alpha_i. = e_i - sum_{j<i} D_ij alpha_j.             beta_.i = e_i - sum_{j<i} gamma_.j C_ji
+//   gamma_.i = beta_.i S_i^-1                            G = sum_i gamma_.i alpha_i.      g = sum_i gamma_.i ze_i
+// where Sv_li = V_l H_i^T and Sw_il = H_i W_l are the 3x3 blocks of H Sigma0 H^T taken from rows / columns.
+__global__ __launch_bounds__(256) void k_ekf_small(EkfState E) {
+    __shared__ double sC[kMarkerMax * 9], sD[kMarkerMax * 9];
+    __shared__ double sBeta[3 * kMarkerMax * 3];
+    __shared__ double sSinv[9];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int m = *E.d_m;
+    const int n3 = 3 * m;
+    const int ld = E.ld;
+    double* Sv = E.d_Sv; double* Sw = E.d_Sw; double* al = E.d_alpha; double* ga = E.d_gamma;
+
+    // Sv[(3l+a)][(3i+b)] = (V_l H_i^T)[a][b] ;  Sw[(3i+a)][(3l+b)] = (H_i W_l)[a][b]
+    for (int p = tid; p < n3 * n3; p += nt) {
+        const int rr = p / n3, cc = p - rr * n3;
+        {
+            const int i = cc / 3, b = cc - 3 * i;
+            const UpdRec& u = E.d_upd[i];
+            const double* v = E.d_V + (size_t)rr * ld;
+            const double* g = &u.Gxm[b * 6];
+            Sv[p] = v[0] * g[0] + v[1] * g[1] + v[2] * g[2] + v[u.li] * g[3] + v[u.li + 1] * g[4] + v[u.li + 2] * g[5];
+        }
+        {
+            const int i = rr / 3, a = rr - 3 * i;
+            const UpdRec& u = E.d_upd[i];
+            const double* w = E.d_Wt + (size_t)cc * ld;
+            const double* g = &u.Gxm[a * 6];
+            Sw[p] = g[0] * w[0] + g[1] * w[1] + g[2] * w[2] + g[3] * w[u.li] + g[4] * w[u.li + 1] + g[5] * w[u.li + 2];
+        }
+        al[p] = 0.0;
+        ga[p] = 0.0;
+    }
+    __syncthreads();
+
+    for (int i = 0; i < m; i++) {
+        // (a) C_ji and (b) D_ij for all j < i
+        for (int p = tid; p < 9 * i; p += nt) {
+            const int j = p / 9, ab = p - 9 * j, a = ab / 3, b = ab - 3 * a;
+            double c = 0, d = 0;
+            for (int q = 0; q < 3 * j + 3; q++) {
+                c += al[(size_t)(3 * j + a) * n3 + q] * Sv[(size_t)q * n3 + 3 * i + b];
+                d += Sw[(size_t)(3 * i + a) * n3 + q] * ga[(size_t)q * n3 + 3 * j + b];
+            }
+            sC[j * 9 + ab] = c;
+            sD[j * 9 + ab] = d;
+        }
+        __syncthreads();
+        // (c) alpha row block i, (d) beta column block i
+        const int w3 = 3 * i + 3;
+        for (int p = tid; p < 3 * w3; p += nt) {
+            const int a = p / w3, c = p - a * w3;
+            double s = (c == 3 * i + a) ? 1.0 : 0.0;
+            for (int j = c / 3; j < i; j++)
+                for (int k = 0; k < 3; k++) s -= sD[j * 9 + a * 3 + k] * al[(size_t)(3 * j + k) * n3 + c];
+            al[(size_t)(3 * i + a) * n3 + c] = s;
+            // beta[r = c][b = a]
+            double t = (c == 3 * i + a) ? 1.0 : 0.0;
+            for (int j = c / 3; j < i; j++)
+                for (int k = 0; k < 3; k++) t -= ga[(size_t)c * n3 + 3 * j + k] * sC[j * 9 + k * 3 + a];
+            sBeta[c * 3 + a] = t;
+        }
+        __syncthreads();
+        // (e) S_i = sum_c alpha[(3i+a)][c] Sv[c][(3i+b)] + R_i ; inverse
+        if (tid == 0) {
+            double S[9];
+            const UpdRec& u = E.d_upd[i];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    double s = 0;
+                    for (int c = 0; c < w3; c++) s += al[(size_t)(3 * i + a) * n3 + c] * Sv[(size_t)c * n3 + 3 * i + b];
+                    S[a * 3 + b] = s + (a == b ? u.r[a] : 0.0);
+                }
+            inv3_pp(S, sSinv);
+        }
+        __syncthreads();
+        // (f) gamma column block i = beta_.i S_i^-1
+        for (int p = tid; p < 3 * w3; p += nt) {
+            const int r = p / 3, b = p - 3 * r;
+            ga[(size_t)r * n3 + 3 * i + b] = sBeta[r * 3] * sSinv[b] + sBeta[r * 3 + 1] * sSinv[3 + b] + sBeta[r * 3 + 2] * sSinv[6 + b];
+        }
+        __syncthreads();
+    }
+    // G = gamma * alpha ; g = gamma * ze
+    for (int p = tid; p < n3 * n3; p += nt) {
+        const int r = p / n3, c = p - r * n3;
+        double s = 0;
+        for (int q = (r > c ? r : c) / 3 * 3; q < n3; q++) s += ga[(size_t)r * n3 + q] * al[(size_t)q * n3 + c];
+        E.d_G[p] = s;
+    }
+    for (int r = tid; r < n3; r += nt) {
+        double s = 0;
+        for (int q = r / 3 * 3; q < n3; q++) s += ga[(size_t)r * n3 + q] * E.d_upd[q / 3].ze[q % 3];
+        E.d_g[r] = s;
+    }
+}
+
+// ---- T = G V (3m x N) and mu += W g ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ekf_T(EkfState E) {
+    const int m = *E.d_m;
+    const int n3 = 3 * m;
+    const int N = 3 + 3 * (*E.d_L);
+    const int ld = E.ld;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int q0 = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (m > 0 && c < N) {
+        for (int q = q0; q < n3; q += 4 * gridDim.y) {
+            double s = 0;
+            for (int p = 0; p < n3; p++) s += E.d_G[(size_t)q * n3 + p] * E.d_V[(size_t)p * ld + c];
+            E.d_T[(size_t)q * ld + c] = s;
+        }
+        if (q0 == 0) {
+            double s = 0;
+            for (int p = 0; p < n3; p++) s += E.d_Wt[(size_t)p * ld + c] * E.d_g[p];
+            E.d_mu[c] += s;                                        // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
+        }
+    }
+}
+
+// ---- Sigma <- Sigma - W T : the one streaming pass over the covariance per frame -----------------------------
+constexpr int UT = 64;        // tile side
+constexpr int UK = 32;        // depth chunk staged through LDS
+
+__global__ __launch_bounds__(256) void k_ekf_update(EkfState E) {
+    __shared__ double sW[UK][UT];
+    __shared__ double sT[UK][UT];
+    const int m = *E.d_m;
+    const int n3 = 3 * m;
+    const int N = 3 + 3 * (*E.d_L);
+    const int ld = E.ld;
+    const int r0 = blockIdx.x * UT, c0 = blockIdx.y * UT;
+    const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6;         // row in tile, group of 16 columns
+    const bool active = m > 0 && r0 < N && c0 < N;                  // uniform per workgroup
+    if (active) {
+        double acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[j] = 0.0;
+        for (int p0 = 0; p0 < n3; p0 += UK) {
+            for (int i = threadIdx.x; i < UK * UT; i += 256) {
+                const int pp = i / UT, x = i - pp * UT;
+                const int p = p0 + pp;
+                sW[pp][x] = (p < n3 && r0 + x < N) ? E.d_Wt[(size_t)p * ld + r0 + x] : 0.0;
+                sT[pp][x] = (p < n3 && c0 + x < N) ? E.d_T[(size_t)p * ld + c0 + x] : 0.0;
+            }
+            __syncthreads();
+            const int pe = min(UK, n3 - p0);
+            for (int pp = 0; pp < pe; pp++) {
+                const double w = sW[pp][tr];
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc[j] += w * sT[pp][tc * 16 + j];
+            }
+            __syncthreads();
+        }
+        const int r = r0 + tr;
+        if (r < N) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int c = c0 + tc * 16 + j;
+                if (c < N) E.d_sigma[(size_t)c * ld + r] -= acc[j];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ekf_export_map(EkfState E) {
+    const int L = *E.d_L;
+    const int ld = E.ld;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < E.max_landmarks; i += gridDim.x * 256) {
+        MapRecord r;
+        if (i < L) {
+            const int li = 3 + 3 * i;
+            r.id = E.d_idx2id[i]; r.index = i;
+            r.x = E.d_mu[li]; r.y = E.d_mu[li + 1]; r.theta = E.d_mu[li + 2];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) r.S[a * 3 + b] = E.d_sigma[(size_t)(li + b) * ld + li + a];
+        } else {
+            r.id = -1; r.index = -1; r.x = r.y = r.theta = 0;
+            for (int k = 0; k < 9; k++) r.S[k] = 0;
+        }
+        E.d_maprec[i] = r;
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------
+template <class T> static hipError_t dalloc(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)); }
+
+hipError_t ekf_alloc(EkfState& E, int max_landmarks) {
+    E = EkfState{};
+    E.max_landmarks = max_landmarks;
+    E.ld = 3 + 3 * max_landmarks;
+    const size_t ld = (size_t)E.ld, n3 = 3 * (size_t)kMarkerMax;
+    hipError_t e;
+#define A(x) if ((e = (x)) != hipSuccess) return e
+    A(dalloc(&E.d_mu, ld));
+    A(dalloc(&E.d_sigma, ld * ld));
+    A(dalloc(&E.d_L, 1));
+    A(dalloc(&E.d_id2idx, kIdTableSize));
+    A(dalloc(&E.d_idx2id, (size_t)max_landmarks));
+    A(dalloc(&E.d_last, kMarkerMax));
+    A(dalloc(&E.d_nlast, 1));
+    A(dalloc(&E.d_pop, kMarkerMax));
+    A(dalloc(&E.d_npop, 1));
+    A(dalloc(&E.d_upd, kMarkerMax));
+    A(dalloc(&E.d_m, 1));
+    A(dalloc(&E.d_V, n3 * ld));
+    A(dalloc(&E.d_Wt, n3 * ld));
+    A(dalloc(&E.d_T, n3 * ld));
+    A(dalloc(&E.d_Sv, n3 * n3));
+    A(dalloc(&E.d_Sw, n3 * n3));
+    A(dalloc(&E.d_alpha, n3 * n3));
+    A(dalloc(&E.d_gamma, n3 * n3));
+    A(dalloc(&E.d_G, n3 * n3));
+    A(dalloc(&E.d_g, n3));
+    A(dalloc(&E.d_maprec, (size_t)max_landmarks));
+    // ArucoSlam::ArucoSlam (aruco_slam.cpp:13-18): mu = 0 (3), sigma = 0 (3x3), empty map
+    A(hipMemset(E.d_mu, 0, ld * sizeof(double)));
+    A(hipMemset(E.d_sigma, 0, ld * ld * sizeof(double)));
+    A(hipMemset(E.d_L, 0, sizeof(int)));
+    A(hipMemset(E.d_id2idx, 0xFF, kIdTableSize * sizeof(int)));
+    A(hipMemset(E.d_idx2id, 0xFF, (size_t)max_landmarks * sizeof(int)));
+    A(hipMemset(E.d_nlast, 0, sizeof(int)));
+    A(hipMemset(E.d_npop, 0, sizeof(int)));
+    A(hipMemset(E.d_m, 0, sizeof(int)));
+#undef A
+    return hipSuccess;
+}
+
+void ekf_free(EkfState& E) {
+    hipFree(E.d_mu); hipFree(E.d_sigma); hipFree(E.d_L); hipFree(E.d_id2idx); hipFree(E.d_idx2id); hipFree(E.d_last);
+    hipFree(E.d_nlast); hipFree(E.d_pop); hipFree(E.d_npop); hipFree(E.d_upd); hipFree(E.d_m); hipFree(E.d_V); hipFree(E.d_Wt);
+    hipFree(E.d_T); hipFree(E.d_Sv); hipFree(E.d_Sw); hipFree(E.d_alpha); hipFree(E.d_gamma); hipFree(E.d_G); hipFree(E.d_g);
+    hipFree(E.d_maprec);
+    E = EkfState{};
+}
+
+void launch_ekf_predict_only(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt) {
+    hipLaunchKernelGGL(k_ekf_predict, dim3(1), dim3(256), 0, st, E, sp, wl, wr, dt);
+}
+void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int do_predict,
+                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr) {
+    hipLaunchKernelGGL(k_ekf_plan, dim3(1), dim3(256), 0, st, E, sp, wl, wr, dt, do_predict, obs, n_markers, ctr);
+}
+void launch_ekf_gather(hipStream_t st, const EkfState& E) {
+    hipLaunchKernelGGL(k_ekf_gather, dim3((E.ld + 255) / 256), dim3(256), 0, st, E);
+}
+void launch_ekf_small(hipStream_t st, const EkfState& E) {
+    hipLaunchKernelGGL(k_ekf_small, dim3(1), dim3(256), 0, st, E);
+}
+void launch_ekf_T(hipStream_t st, const EkfState& E) {
+    hipLaunchKernelGGL(k_ekf_T, dim3((E.ld + 63) / 64, 16), dim3(256), 0, st, E);
+}
+void launch_ekf_update(hipStream_t st, const EkfState& E) {
+    const int t = (E.ld + UT - 1) / UT;
+    hipLaunchKernelGGL(k_ekf_update, dim3(t, t), dim3(256), 0, st, E);
+}
+void launch_ekf_export_map(hipStream_t st, const EkfState& E) {
+    hipLaunchKernelGGL(k_ekf_export_map, dim3((E.max_landmarks + 255) / 256), dim3(256), 0, st, E);
+}
+
+} // namespace aslam

@@ -1,0 +1,140 @@
+/* aruco_slam_hip.h — C-ABI of libaruco_slam_hip.so, the MI355X (gfx950) drop-in for the hot path of
+ * gitAugust/Aruco_Slam: per-frame ArUco detect + per-marker pose + SE(2) EKF-SLAM predict/update.
+ *
+ * The reference has no FFI layer; its boundary is the C++ class `ArucoSlam`
+ * (include/aruco_slam/aruco_slam.h:101-193) whose headers drag in Eigen, OpenCV and ROS.  This header is
+ * the POD-only surface a maintainer binds instead; include/aruco_slam/aruco_slam_hip.hpp wraps it in a
+ * class with the reference's method names.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative ASLAM_E_* code on failure (never
+ * throws); aslam_last_error() gives the text.  A context is bound to one HIP device and one HIP stream and
+ * is NOT thread-safe (the reference relies on the single-threaded ROS spinner, aruco_slam_node.cpp:79).
+ * Pointers are plain host pointers unless the parameter name starts with d_.  There is no CPU fallback: on a
+ * machine without a usable gfx950 device aslam_create fails with ASLAM_E_NO_DEVICE.
+ */
+#ifndef ARUCO_SLAM_HIP_H
+#define ARUCO_SLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct aslam_ctx aslam_ctx;
+
+enum {
+    ASLAM_OK = 0,
+    ASLAM_E_INVALID = -1,     /* bad argument */
+    ASLAM_E_NO_DEVICE = -2,   /* no HIP device / HIP runtime error at start-up */
+    ASLAM_E_HIP = -3,         /* HIP runtime error during a call */
+    ASLAM_E_CAPACITY = -4,    /* a device-side list overflowed (see aslam_last_error) */
+    ASLAM_E_STATE = -5        /* call out of order (e.g. image before camera parameters) */
+};
+
+/* Mirrors struct ArucoSlamIniteData (aruco_slam.h:40-60) plus device/capacity settings.
+ * r2c_* is transformStamped_r2c (base_link <- camera_frame_optical); only translation x,y enter the
+ * arithmetic (aruco_slam.cpp:359-360), the rest is carried for the visualisation getters. */
+typedef struct {
+    double Q_k, R_x, R_y, R_theta;       /* parameters.yaml:5-8 */
+    double kl, kr, b;                    /* parameters.yaml:11-13 */
+    double marker_length;                /* parameters.yaml:17 */
+    int    markers_dictionary;           /* parameters.yaml:16 ; 16 = DICT_ARUCO_ORIGINAL */
+    float  useful_distance_threshold;    /* aruco_slam.h:58, default 3 (the YAML key never takes effect) */
+    double r2c_t[3], r2c_q[4];
+    int    device_id;
+    int    max_landmarks;                /* capacity of the EKF state: N_max = 3 + 3*max_landmarks */
+    int    max_rows, max_cols;           /* largest frame that will be handed over */
+    int    max_batch;                    /* frames staged / processed per call of the *_staged functions */
+    int    persistent_waves;             /* wavefronts of the work-queue kernels; 0 = default (2048) */
+    unsigned cap_starts_per_frame;       /* 0 = defaults */
+    unsigned cap_contours_per_frame;
+    unsigned cap_points_per_frame;
+} aslam_init;
+
+/* fills *init with the reference's shipped parameters.yaml values and sane capacities */
+void aslam_default_init(aslam_init* init);
+
+/* ArucoSlam::ArucoSlam(const ArucoSlamIniteData&)  — aruco_slam.h:109, aruco_slam.cpp:3-19 */
+int  aslam_create(const aslam_init* init, aslam_ctx** out);
+void aslam_destroy(aslam_ctx* ctx);
+const char* aslam_last_error(const aslam_ctx* ctx);
+
+/* ArucoSlam::setCameraParameters(pair<cv::Mat K, cv::Mat D>) — aruco_slam.h:129-133; K row-major 3x3, D n x 1 */
+int aslam_set_camera(aslam_ctx* ctx, const double K[9], const double* D, int nD);
+
+/* ArucoSlam::addEncoder(wl, wr) — aruco_slam.h:116, aruco_slam.cpp:21-74.  t_now_sec stands in for the two
+ * ros::Time::now() calls (:26,:31-32); the adapter passes ros::Time::now().toSec(). */
+int aslam_add_encoder(aslam_ctx* ctx, double wl, double wr, double t_now_sec);
+
+/* ArucoSlam::addImage(const cv::Mat&) — aruco_slam.h:122, aruco_slam.cpp:76-287.  px is borrowed for the
+ * call only (cv_bridge::toCvShare aliasing, aruco_slam_node.cpp:93); channels 1 (gray) or 3 (bgr8). */
+int aslam_add_image(aslam_ctx* ctx, const uint8_t* px, int rows, int cols, int channels, size_t step_bytes);
+
+/* mu_ / sigma_ (aruco_slam.h:182-183).  sigma is written column-major with leading dimension N, exactly
+ * Eigen::MatrixXd's layout.  Pass NULL for mu/sigma to query N only. */
+int aslam_get_state(aslam_ctx* ctx, int* N, double* mu, double* sigma);
+/* overwrite the state (no reference counterpart: used by tests and warm starts) */
+int aslam_set_state(aslam_ctx* ctx, int N, const double* mu, const double* sigma, const int* landmark_ids);
+
+/* marker_corners / IDs / rvs / tvs of getObservations (aruco_slam.cpp:309-314) for the last frame of the last
+ * call; corners M*8 floats (x0,y0,...,x3,y3), rvecs/tvecs M*3 doubles.  Arrays may be NULL. */
+int aslam_get_detections(aslam_ctx* ctx, int* M, int* ids, float* corners, double* rvecs, double* tvecs);
+/* the observations popped from obs_ in pop order (aruco_slam.cpp:92-95) for the last frame: id, landmark index
+ * at push time (-1 new), action (0 augment, 1 update, 2 stationary no-op), (x,y,theta), diag(R). */
+int aslam_get_observations(aslam_ctx* ctx, int* n, int* ids, int* idx, int* action, double* xyth, double* Rdiag);
+/* aruco_id_map inverted: ids[i] = marker id of landmark index i (aruco_slam.h:164) */
+int aslam_get_landmark_ids(aslam_ctx* ctx, int* L, int* ids);
+
+/* ---- device-resident stream API (throughput path: frames staged once in HBM) -------------------------
+ * aslam_stage_frames uploads nframes tightly packed frames into slots [slot0, slot0+nframes);
+ * aslam_stage_encoders stores, per slot, the encoder sample (wl, wr, dt) that precedes that frame;
+ * aslam_run_staged(first, count, with_ekf) then runs, entirely on the device and asynchronously on the context's
+ * stream: detection + pose for all `count` frames batched, followed (with_ekf != 0) by `count` sequential
+ * addEncoder(dt) + addImage EKF steps.  aslam_sync waits and reports device-side overflow. */
+int aslam_stage_frames(aslam_ctx* ctx, int slot0, const uint8_t* frames, int nframes, int rows, int cols,
+                       int channels, size_t step_bytes, size_t frame_stride_bytes);
+int aslam_stage_encoders(aslam_ctx* ctx, int slot0, int n, const double* wl, const double* wr, const double* dt);
+int aslam_run_staged(aslam_ctx* ctx, int first, int count, int with_ekf);
+int aslam_sync(aslam_ctx* ctx);
+/* per-slot results of the last aslam_run_staged */
+int aslam_get_slot_detections(aslam_ctx* ctx, int slot, int* M, int* ids, float* corners, double* rvecs, double* tvecs);
+int aslam_get_slot_raw_observations(aslam_ctx* ctx, int slot, int* n, int* ids, int* valid, double* xyth, double* Rdiag);
+
+/* cv::aruco::detectMarkers + estimatePoseSingleMarkers on a batch of independent host frames, no EKF
+ * (BASELINE config 5).  counts[nframes]; ids/corners/rvecs/tvecs hold max_per_frame entries per frame. */
+int aslam_detect_batch(aslam_ctx* ctx, const uint8_t* frames, int nframes, int rows, int cols, int channels,
+                       size_t step_bytes, size_t frame_stride_bytes, int max_per_frame, int* counts, int* ids,
+                       float* corners, double* rvecs, double* tvecs);
+
+/* ---- landmark-map record for the multi-GPU gather ---------------------------------------
+ * Fixed-size record per landmark: { int32 id, int32 index, f64 x, y, theta, f64 Sigma_ll[9] } = 104 bytes.
+ * Writes max_landmarks records (unused ones have id = -1) to a host or device buffer. */
+int aslam_export_map(aslam_ctx* ctx, void* dst, int dst_is_device);
+#define ASLAM_MAP_RECORD_BYTES 104
+
+/* ---- instrumentation ---------------------------------------------------------------------------------
+ * Stage taps used by the parity tests (tests/): what each detector stage produced for a staged slot. */
+int aslam_debug_get_nbr(aslam_ctx* ctx, int slot, int scale, uint8_t* out /* rows*cols */);
+int aslam_debug_get_contours(aslam_ctx* ctx, int slot, int scale, int max_contours, long long max_points,
+                             int* n_contours, int* sizes, int* keys, int* points_xy, long long* n_points);
+int aslam_debug_get_candidates(aslam_ctx* ctx, int slot, int stage /*0 quads (unordered), 2 final*/, int max,
+                               int* n, float* corners, int* sizes, int* ids);
+/* HIP-event timing of each kernel family on the context's stream, accumulated since the last reset:
+ * names[i] (static strings), calls[i], total_ms[i]; returns the number of entries. */
+int aslam_profile_enable(aslam_ctx* ctx, int on);
+int aslam_profile_reset(aslam_ctx* ctx);
+int aslam_profile_get(aslam_ctx* ctx, int max, const char** names, int* calls, double* total_ms);
+
+/* deterministic synthetic frame renderer (input generation for tests and bench; not on the hot path).
+ * markers: per marker 12 doubles = rotation (row-major 3x3, marker->camera) then translation;
+ * ids: dictionary id per marker.  Writes gray frames (rows*cols) into staged slots (on_device=1) or to out. */
+int aslam_synth_render(aslam_ctx* ctx, int slot, int rows, int cols, const double K[9], int n_markers, const int* ids,
+                       const double* poses, double marker_length, int background, int noise_amp, unsigned seed,
+                       int supersample, uint8_t* out_host /* may be NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
