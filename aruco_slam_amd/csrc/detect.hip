@@ -696,16 +696,7 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
             // keep the wave convergent: the shuffles above are executed by all lanes or by none
         }
         if (lane == 0) {
-            if (id >= 0 && rot != 0) {
-                // std::rotate(begin, begin + 4 - rot, end): new[j] = old[(j + 4 - rot) % 4]
-                float o[8];
-                for (int i = 0; i < 8; i++) o[i] = fc->c[i];
-                for (int j = 0; j < 4; j++) {
-                    int sidx = (j + 4 - rot) & 3;
-                    fc->c[2 * j] = o[2 * sidx];
-                    fc->c[2 * j + 1] = o[2 * sidx + 1];
-                }
-            }
+            fc->pad[0] = rot;        // corner rotation is applied when the marker list is built (k_pose)
             fc->id = id;
         }
         __syncthreads();

@@ -325,7 +325,13 @@ __global__ __launch_bounds__(128) void k_pose(const FinalCand* __restrict__ fina
             if (fin[i].id >= 0) {
                 if (k < kMarkerMax) {
                     sId[k] = fin[i].id;
-                    for (int j = 0; j < 8; j++) sC[k][j] = fin[i].c[j];
+                    // _identifyOneCandidate: std::rotate(begin, begin + 4 - rot, end) -> new[j] = old[(j + 4 - rot) % 4]
+                    const int rot = fin[i].pad[0];
+                    for (int j = 0; j < 4; j++) {
+                        const int sidx = (j + 4 - rot) & 3;
+                        sC[k][2 * j] = fin[i].c[2 * sidx];
+                        sC[k][2 * j + 1] = fin[i].c[2 * sidx + 1];
+                    }
                     k++;
                 } else {
                     atomicOr(&ctr->overflow, (unsigned)kOvfMarkers);
