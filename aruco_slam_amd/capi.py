@@ -218,8 +218,8 @@ class Context:
     # -- staged (device-resident) stream API ------------------------------------------------------
     def stage_frames(self, frames, slot0=0):
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
-        if frames.ndim == 2:
-            frames = frames[None]
+        if frames.ndim == 2 or (frames.ndim == 3 and frames.shape[-1] == 3):
+            frames = frames[None]                      # one gray (rows, cols) or one bgr8 (rows, cols, 3) frame
         n, rows, cols = frames.shape[:3]
         ch = 1 if frames.ndim == 3 else frames.shape[3]
         self._ck(self.lib.aslam_stage_frames(self.h, int(slot0), _ptr(frames, _u8p), n, rows, cols, ch, cols * ch, rows * cols * ch))

@@ -1,0 +1,154 @@
+"""GPU parity tests (run on a real MI355X): HIP path through the C-ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from aruco_slam_amd import capi, synth
+from oracle import pyoracle as orc
+import parity_common as pc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_the_one_loaded():
+    lib = capi.load()
+    assert capi.lib_path().endswith("libaruco_slam_hip.so")
+    assert lib is not None
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3"])
+def test_detector_stage_parity_full_size(name):
+    """threshold / contours / candidates / ids / corners bit-exact at BASELINE.json's frame sizes."""
+    cfg = synth.CONFIGS[name]
+    w = synth.PanelWorld(cfg)
+    B = 4
+    ctx = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=B, max_landmarks=16)
+    D = np.zeros(5)
+    ctx.set_camera(w.K, D)
+    frs = [w.frame(i * (w.frames_per_panel // 2 + 1)) for i in range(B)]
+    imgs = [ctx.synth_render(i, cfg.rows, cfg.cols, w.K, fr.ids, fr.poses, noise_amp=3, seed=10 + i) for i, fr in enumerate(frs)]
+    ctx.run_staged(0, B, with_ekf=False)
+    ctx.sync()
+    for i in range(B):
+        ids, corners, rv, tv = pc.check_stages(ctx, i, imgs[i], expect_ids=frs[i].ids)
+        pc.check_poses(ids, corners, rv, tv, w.K, D)
+
+
+def test_detector_bgr_input_and_distortion():
+    rows, cols, f = 480, 640, 450.0
+    ids, poses, K = synth.simple_scene(rows, cols, f, 4, seed=3)
+    D = np.array([0.0416, -0.0477, -0.00326, -0.00399, 0.0111])      # plumb_bob of the reference's default.yaml:16-20
+    ctx = capi.Context(max_rows=rows, max_cols=cols, max_batch=1, max_landmarks=8)
+    ctx.set_camera(K, D)
+    gray = ctx.synth_render(0, rows, cols, K, ids, poses, noise_amp=2, seed=1)
+    rng = np.random.RandomState(0)
+    bgr = np.stack([np.clip(gray.astype(int) + rng.randint(-6, 7, gray.shape), 0, 255)] * 3, axis=-1).astype(np.uint8)
+    bgr[..., 1] = gray
+    ctx.stage_frames(bgr)
+    ctx.run_staged(0, 1, with_ekf=False)
+    ctx.sync()
+    g = orc.bgr2gray(bgr)
+    ids_g, c_g, rv, tv = pc.check_stages(ctx, 0, g)
+    ids_o, c_o = orc.detect(bgr)
+    assert np.array_equal(ids_o, ids_g) and np.array_equal(c_o, c_g)
+    assert len(ids_g) == 4
+    pc.check_poses(ids_g, c_g, rv, tv, K, D)
+
+
+def test_contours_on_degenerate_images():
+    """random / blocky / thin-line images: every border the sequential Suzuki scan finds, in its order, point for point"""
+    rows, cols = 240, 320
+    ctx = capi.Context(max_rows=rows, max_cols=cols, max_batch=1, max_landmarks=4, cap_contours_per_frame=1 << 15,
+                       cap_points_per_frame=1 << 21, cap_starts_per_frame=1 << 17)
+    ctx.set_camera(synth.camera_matrix(rows, cols, 200.0), np.zeros(5))
+    rng = np.random.RandomState(7)
+    for trial in range(12):
+        kind = trial % 4
+        if kind == 0:
+            img = rng.randint(0, 256, (rows, cols)).astype(np.uint8)
+        elif kind == 1:
+            img = np.kron(rng.randint(0, 256, (rows // 8, cols // 8)), np.ones((8, 8))).astype(np.uint8)
+        elif kind == 2:
+            img = np.kron(rng.randint(0, 256, (rows // 3, cols // 4)), np.ones((3, 4))).astype(np.uint8)[:rows, :cols]
+            img = np.ascontiguousarray(np.pad(img, ((0, rows - img.shape[0]), (0, cols - img.shape[1])), mode="edge"))
+        else:
+            img = np.full((rows, cols), 210, np.uint8)
+            for _ in range(60):
+                x0, y0 = rng.randint(0, cols), rng.randint(0, rows)
+                img[y0:y0 + rng.randint(1, 40), x0:x0 + rng.randint(1, 40)] = rng.randint(0, 256)
+        ctx.stage_frames(img)
+        try:
+            ctx.run_staged(0, 1, with_ekf=False)
+            ctx.sync()
+        except capi.AslamError as e:
+            assert e.code == -4            # candidate-list capacity on pure-noise input is reported, never silent
+            continue
+        pc.check_stages(ctx, 0, img)
+
+
+def test_slam_sequence_cfg1_literal_oracle():
+    """cfg1 (640x480, 4 markers/frame, 12 landmarks): per-frame comparison against the LITERAL dense-O(N^3) oracle"""
+    cfg = synth.CONFIGS["cfg1"]
+    w = synth.PanelWorld(cfg)
+    stats, ctx, o = pc.run_slam_sequence(cfg, w.lap_length() + 9, batch=8, literal=True, per_frame_check=True)
+    assert stats["augments"] == w.L
+    assert stats["updates"] > 4 * w.frames_per_panel
+    assert stats["max_sigma"] < pc.TIGHT and stats["max_mu"] < 1e-9
+
+
+def test_slam_sequence_cfg2_headline():
+    """cfg2 (1280x720, 20 markers/frame, 200 landmarks): whole lap, batched, against the rank-3 sequential oracle"""
+    cfg = synth.CONFIGS["cfg2"]
+    w = synth.PanelWorld(cfg)
+    stats, ctx, o = pc.run_slam_sequence(cfg, w.lap_length() + 24, batch=24, literal=False)
+    assert stats["augments"] == w.L                                  # all 200 landmarks entered the map via the augment path
+    mu, S = ctx.get_state()
+    assert mu.size == 3 + 3 * w.L
+    assert stats["max_sigma"] < pc.TIGHT
+    # size-independent properties: symmetric to rounding, positive diagonal
+    assert np.abs(S - S.T).max() <= 1e-9 * np.abs(S).max()
+    assert (np.diag(S) > 0).all()
+
+
+def test_single_frame_api_matches_staged_api():
+    """aslam_add_encoder / aslam_add_image (the ArucoSlam::addEncoder / addImage surface) == staged stream API"""
+    cfg = synth.CONFIGS["cfg1"]
+    w = synth.PanelWorld(cfg)
+    D = np.zeros(5)
+    a = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=4, max_landmarks=16)
+    b = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=4, max_landmarks=16)
+    a.set_camera(w.K, D); b.set_camera(w.K, D)
+    frs = [w.frame(i) for i in range(4)]
+    imgs = [a.synth_render(i, cfg.rows, cfg.cols, w.K, fr.ids, fr.poses, noise_amp=1, seed=i) for i, fr in enumerate(frs)]
+    a.stage_encoders([f.wl for f in frs], [f.wr for f in frs], [f.dt for f in frs])
+    a.run_staged(0, 4, with_ekf=True); a.sync()
+    t = 0.0
+    for fr, img in zip(frs, imgs):
+        t += fr.dt
+        b.add_encoder(fr.wl, fr.wr, t)
+        b.add_image(img)
+    mu_a, S_a = a.get_state(); mu_b, S_b = b.get_state()
+    assert np.array_equal(mu_a, mu_b) and np.array_equal(S_a, S_b)
+
+
+def test_no_image_work_before_first_encoder_message():
+    cfg = synth.CONFIGS["cfg1"]
+    w = synth.PanelWorld(cfg)
+    c = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=1, max_landmarks=16)
+    c.set_camera(w.K, np.zeros(5))
+    fr = w.frame(0)
+    img = c.synth_render(0, cfg.rows, cfg.cols, w.K, fr.ids, fr.poses)
+    c.add_image(img)                                # aruco_slam.cpp:84-85: ignored until is_init_
+    mu, S = c.get_state()
+    assert mu.size == 3 and not mu.any() and not S.any()
+
+
+def test_export_map_records():
+    cfg = synth.CONFIGS["cfg1"]
+    stats, ctx, o = pc.run_slam_sequence(cfg, 6, batch=6, literal=False)
+    rec = np.frombuffer(ctx.export_map().tobytes(), dtype=np.dtype([("id", "<i4"), ("index", "<i4"), ("x", "<f8"), ("y", "<f8"),
+                                                                    ("theta", "<f8"), ("S", "<f8", (9,))]))
+    mu, S = ctx.get_state()
+    L = (mu.size - 3) // 3
+    assert (rec["id"][:L] == ctx.get_landmark_ids()).all() and (rec["id"][L:] == -1).all()
+    assert np.allclose(rec["x"][:L], mu[3::3]) and np.allclose(rec["theta"][:L], mu[5::3])
+    assert np.allclose(rec["S"][0].reshape(3, 3), S[3:6, 3:6])

@@ -1,0 +1,105 @@
+"""Small-size parity of the kernel LOGIC without a GPU: the same kernel sources compiled against the CPU emulation
+of the HIP subset (tests/hipemu) are driven through the same C-ABI and compared with the oracle.  On a box with a GPU
+these run against the real library instead."""
+import numpy as np
+import pytest
+
+from aruco_slam_amd import capi, synth
+from oracle import pyoracle as orc
+import parity_common as pc
+
+
+def small_ctx(rows, cols, batch=1, **kw):
+    args = dict(max_rows=rows, max_cols=cols, max_batch=batch, persistent_waves=4, max_landmarks=16)
+    args.update(kw)
+    return capi.Context(**args)
+
+
+def test_detector_stages_small_scene():
+    rows, cols, f = 240, 320, 300.0
+    ids, poses, K = synth.simple_scene(rows, cols, f, 3, seed=1, tz=(0.9, 1.4))
+    ctx = small_ctx(rows, cols)
+    D = np.zeros(5)
+    ctx.set_camera(K, D)
+    img = ctx.synth_render(0, rows, cols, K, ids, poses, noise_amp=3, seed=5)
+    ctx.run_staged(0, 1, with_ekf=False)
+    ctx.sync()
+    got_ids, corners, rv, tv = pc.check_stages(ctx, 0, img, expect_ids=ids)
+    pc.check_poses(got_ids, corners, rv, tv, K, D)
+
+
+def test_detector_bgr_and_odd_size():
+    rows, cols, f = 150, 205, 200.0            # not a multiple of the 64x32 tile
+    ids, poses, K = synth.simple_scene(rows, cols, f, 1, seed=2, tz=(0.7, 0.9))
+    ctx = small_ctx(rows, cols)
+    ctx.set_camera(K, np.zeros(5))
+    gray = ctx.synth_render(0, rows, cols, K, ids, poses, noise_amp=2, seed=1)
+    bgr = np.stack([gray, np.roll(gray, 1, 1), gray], -1)
+    ctx.stage_frames(bgr)
+    ctx.run_staged(0, 1, with_ekf=False)
+    ctx.sync()
+    pc.check_stages(ctx, 0, orc.bgr2gray(bgr))
+    ids_o, c_o = orc.detect(bgr)
+    ids_g, c_g, _, _ = ctx.get_slot_detections(0)
+    assert np.array_equal(ids_o, ids_g) and np.array_equal(c_o, c_g)
+
+
+def test_contours_degenerate_images():
+    rows, cols = 64, 96
+    ctx = small_ctx(rows, cols, cap_starts_per_frame=1 << 15, cap_contours_per_frame=1 << 13, cap_points_per_frame=1 << 19)
+    ctx.set_camera(synth.camera_matrix(rows, cols, 100.0), np.zeros(5))
+    rng = np.random.RandomState(0)
+    checked = 0
+    for trial in range(8):
+        if trial % 2 == 0:
+            img = np.kron(rng.randint(0, 256, (rows // 4, cols // 4)), np.ones((4, 4))).astype(np.uint8)
+        else:
+            img = np.full((rows, cols), 200, np.uint8)
+            for _ in range(25):
+                x0, y0 = rng.randint(0, cols), rng.randint(0, rows)
+                img[y0:y0 + rng.randint(1, 30), x0:x0 + rng.randint(1, 30)] = rng.randint(0, 256)
+        ctx.stage_frames(img)
+        try:
+            ctx.run_staged(0, 1, with_ekf=False)
+            ctx.sync()
+        except capi.AslamError as e:
+            assert e.code == -4
+            continue
+        pc.check_stages(ctx, 0, img)
+        checked += 1
+    assert checked >= 4
+
+
+def test_empty_and_blank_frames():
+    rows, cols = 64, 96
+    ctx = small_ctx(rows, cols)
+    ctx.set_camera(synth.camera_matrix(rows, cols, 100.0), np.zeros(5))
+    for value in (0, 128, 255):
+        ctx.stage_frames(np.full((rows, cols), value, np.uint8))
+        ctx.run_staged(0, 1, with_ekf=False)
+        ctx.sync()
+        assert len(ctx.get_slot_detections(0)[0]) == 0
+
+
+def test_slam_sequence_small_literal():
+    cfg = synth.SceneConfig(rows=240, cols=320, f=225.0, grid=(2, 2), n_panels=3, col_spacing=0.9, row_spacing=0.7, step=0.05,
+                            tz_far=2.4, tz_near=1.9, r2c=(0.1, -0.05))
+    w = synth.PanelWorld(cfg)
+    stats, ctx, o = pc.run_slam_sequence(cfg, w.lap_length() + 5, batch=4, literal=True, per_frame_check=True,
+                                         ctx_kwargs=dict(persistent_waves=4))
+    assert stats["augments"] == w.L and stats["updates"] > 20
+    assert stats["max_sigma"] < pc.TIGHT
+
+
+def test_argument_validation():
+    ctx = small_ctx(64, 96)
+    with pytest.raises(capi.AslamError):
+        ctx.stage_frames(np.zeros((65, 96), np.uint8))        # larger than max_rows
+    with pytest.raises(capi.AslamError):
+        ctx.run_staged(0, 2, with_ekf=False)                   # outside max_batch
+    ctx.stage_frames(np.zeros((64, 96), np.uint8))
+    with pytest.raises(capi.AslamError) as e:
+        ctx.run_staged(0, 1, with_ekf=False)                   # camera parameters not set
+    assert e.value.code == -5
+    with pytest.raises(capi.AslamError):
+        capi.Context(markers_dictionary=10)                    # only DICT_ARUCO_ORIGINAL can be generated offline
