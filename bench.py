@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the ArUco EKF-SLAM hot path (detect + pose + EKF) on MI355X.
+
+Workload (BASELINE.json configs[1]): one 1280x720 gray camera stream per GPU, 20 markers in view per frame, a
+200-landmark map (built before timing by driving one lap through the reference's own augment path), one
+addEncoder + one addImage per frame.  A "step" = one pass of the hot path over one batch of `--batch` consecutive
+frames of the stream, frames already resident in HBM: detection + pose run batched over the step's frames, the
+EKF steps run in stream order.  N > 1: one independent stream per rank (weak scaling), plus one RCCL all-gather
+of the landmark map per step.
+
+Prints ONE JSON line (see the task contract) with `roofline` (dominant kernel, HIP-event timed inside the timed
+region on the library's stream) and `cpu_baseline` (the CPU oracle = port of the reference algorithm, 1 thread, on a
+bounded sample of the same frames).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=78, help="frames per step")
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--cpu-sample", type=int, default=195, help="frames timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-ekf", action="store_true", help="detect + pose only (BASELINE config 5 style)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch                      # before the C-ABI library so both share one HIP runtime instance
+    import torch.distributed as dist
+    import numpy as np
+    from aruco_slam_amd import capi, synth
+    from aruco_slam_amd.dist import MapGather
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = synth.CONFIGS[args.config]
+    world_scene = synth.PanelWorld(cfg)
+    lap = world_scene.lap_length()
+    B = min(args.batch, lap)
+    ctx = capi.Context(device_id=local_rank, max_rows=cfg.rows, max_cols=cfg.cols, max_batch=lap,
+                       max_landmarks=world_scene.L + 8)
+    D = np.zeros(5)
+    ctx.set_camera(world_scene.K, D)
+
+    # ---- stage one lap of the stream in HBM (rendered on the device; different seed per rank = different stream)
+    frames = [world_scene.frame(i) for i in range(lap)]
+    host_sample = []
+    for i, fr in enumerate(frames):
+        img = ctx.synth_render(i, cfg.rows, cfg.cols, world_scene.K, fr.ids, fr.poses, noise_amp=2, seed=1000 * rank + i,
+                               download=(rank == 0 and i < args.cpu_sample))
+        if img is not None:
+            host_sample.append(img)
+    ctx.stage_encoders([f.wl for f in frames], [f.wr for f in frames], [f.dt for f in frames])
+    # the first frame of every later lap is preceded by the turn that closes the polygon, not by the arming sample
+    turn = world_scene.frame(lap)
+    with_ekf = not args.no_ekf
+
+    def run_range(first, count):
+        ctx.run_staged(first, count, with_ekf=with_ekf)
+
+    # ---- build the 200-landmark map: one full lap through the augment path (untimed)
+    if with_ekf:
+        run_range(0, lap)
+        ctx.sync()
+        mu, _ = ctx.get_state()
+        assert mu.size == 3 + 3 * world_scene.L, f"map has {(mu.size - 3) // 3} landmarks, expected {world_scene.L}"
+        ctx.stage_encoders([turn.wl], [turn.wr], [turn.dt], slot0=0)
+    gather = MapGather(ctx, device=f"cuda:{local_rank}") if world > 1 else None
+
+    pos = [0]
+
+    def step():
+        first = pos[0]
+        if first + B <= lap:
+            run_range(first, B)
+        else:
+            run_range(first, lap - first)
+            run_range(0, B - (lap - first))
+        pos[0] = (first + B) % lap
+        if gather is not None:
+            ctx.sync()
+            gather.gather()
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up with full per-kernel HIP-event profiling: finds the dominant kernel
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(max(args.warmup, 1)):
+        step()
+    ctx.sync()
+    prof = ctx.profile_get()
+    dominant = max(prof, key=lambda k: prof[k][1])
+    ctx.profile_enable(False)
+    ctx.profile_reset()
+
+    # ---- timed region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # observations actually fused per frame (the covariance gate, aruco_slam.cpp:367, drops some)
+    ids, idx, act, _, _ = ctx.get_observations() if with_ekf else (np.zeros(0),) * 5
+
+    # ---- roofline of the dominant kernel: a second, identical pass with HIP events on that kernel only
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    prof2 = ctx.profile_get()
+    ctx.profile_enable(False)
+    calls, total_ms = prof2[dominant]
+    N = 3 + 3 * world_scene.L
+    per_frame_bytes = {                                   # share of SURVEY §8(d)'s ALG_BYTES each kernel family is charged with
+        "k_threshold": cfg.rows * cfg.cols, "k_trace": cfg.rows * cfg.cols, "k_quads": cfg.rows * cfg.cols,
+        "k_assemble": 84 * world_scene.M, "k_identify": cfg.rows * cfg.cols, "k_pose": 84 * world_scene.M,
+        "k_ekf_plan": 16 * N, "k_ekf_gather": 8 * N * N, "k_ekf_small": 8 * N * N, "k_ekf_T": 8 * N * N, "k_ekf_update": 16 * N * N,
+    }
+    frames_per_launch = B if not dominant.startswith("k_ekf") else 1
+    launches = max(calls, 1)
+    avg_s = total_ms / 1e3 / launches
+    alg_bytes = per_frame_bytes[dominant] * (args.steps * B / launches if not dominant.startswith("k_ekf") else 1)
+    achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 6), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                "alg_bytes_per_launch": int(alg_bytes),
+                "kernel_ms_per_step": {k: round(v[1] / max(args.steps, 1), 4) for k, v in prof2.items()}}
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, on a bounded sample of the same stream
+    cpu = None
+    if rank == 0 and args.cpu_sample > 0 and host_sample:
+        from oracle import pyoracle as orc
+        o = orc.Slam(literal=False)
+        o.set_camera(world_scene.K, D)
+        tc = time.perf_counter()
+        t_now = 0.0
+        for i, img in enumerate(host_sample):
+            t_now += frames[i].dt
+            o.add_encoder(frames[i].wl, frames[i].wr, t_now)
+            if with_ekf:
+                o.add_image(img)
+            else:
+                ids_o, c_o = orc.detect(img)
+                for c in c_o:
+                    orc.solve_pnp(c, cfg.marker_length, world_scene.K, D)
+        dtc = time.perf_counter() - tc
+        cpu = {"value": round(len(host_sample) / dtc, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"first {len(host_sample)} frames of the same stream through oracle/ (detect+PnP+"
+                         f"{'rank-3 EKF, map growing to ' + str((o.get_state()[0].size - 3) // 3) + ' landmarks' if with_ekf else 'no EKF'}"
+                         f"), {dtc:.1f} s, g++ -O2 scalar, OpenCV/Eigen unavailable"}
+
+    if rank == 0:
+        total_frames = world * args.steps * B
+        out = {
+            "metric": "frames/s (detect+pose+EKF) at 1280x720, 20 markers, 200 landmarks" if args.config == "cfg2" and with_ekf
+                      else f"frames/s ({'detect+pose+EKF' if with_ekf else 'detect+pose'}) {args.config}",
+            "value": round(total_frames / elapsed, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {cfg.cols}x{cfg.rows} gray stream per GPU, {world_scene.M} markers/frame, "
+                                   f"{world_scene.L}-landmark EKF (N={N}), frames resident in HBM",
+                       "frames_per_step": B, "streams": world, "ekf": with_ekf,
+                       "updates_in_last_frame": int((act == 1).sum()) if with_ekf else 0,
+                       "map_gather": "rccl all_gather per step" if world > 1 else "none"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
