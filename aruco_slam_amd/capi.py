@@ -17,7 +17,7 @@ ASLAM_OK = 0
 E_NAMES = {-1: "INVALID", -2: "NO_DEVICE", -3: "HIP", -4: "CAPACITY", -5: "STATE"}
 MAP_RECORD_BYTES = 104
 MARKER_MAX = 128
-CAND_MAX = 512
+CAND_MAX = 2048
 
 
 class AslamInit(C.Structure):

@@ -9,7 +9,7 @@
 namespace aslam {
 
 constexpr int kScales = 3;        // adaptive-threshold windows 3, 13, 23 (DetectorParameters defaults)
-constexpr int kCandMax = 512;     // quad candidates kept per frame
+constexpr int kCandMax = 2048;    // quad candidates kept per frame
 constexpr int kMarkerMax = 128;   // identified markers / observations per frame
 constexpr int kDictMaxCells = 9;  // markerSize + 2 border cells <= 9 (7x7 dictionaries)
 constexpr int kCellPx = 8;        // perspectiveRemovePixelPerCell (3.2.0 default)

@@ -406,24 +406,29 @@ __global__ __launch_bounds__(64) void k_quads(DetectCfg cfg, Counters* ctr, cons
 // ------------------------------------------------------------------------------------------------
 // k_assemble : one workgroup per frame
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_assemble(DetectCfg cfg, Counters* ctr, const CandRec* __restrict__ cands,
-                                                  const unsigned* __restrict__ n_cand, FinalCand* __restrict__ finals,
-                                                  unsigned* __restrict__ n_final, IdentWork* __restrict__ work) {
+constexpr int kPairMax = 4096;     // near pairs per frame (_filterTooCloseCandidates)
+constexpr int AT = 1024;           // threads of k_assemble
+
+__global__ __launch_bounds__(1024) void k_assemble(DetectCfg cfg, Counters* ctr, const CandRec* __restrict__ cands,
+                                                   const unsigned* __restrict__ n_cand, FinalCand* __restrict__ finals,
+                                                   unsigned* __restrict__ n_final, IdentWork* __restrict__ work) {
     __shared__ CandRec sIn[kCandMax];
     __shared__ CandRec sC[kCandMax];
-    __shared__ unsigned nearBits[kCandMax][kCandMax / 32];
+    __shared__ unsigned sPair[kPairMax];           // (i << 16) | j, unordered
+    __shared__ unsigned sPairSorted[kPairMax];     // lexicographic (i, j) order
     __shared__ unsigned char removed[kCandMax];
     __shared__ int outPos[kCandMax];
+    __shared__ unsigned sNPair;
     const int tid = threadIdx.x;
     const int f = blockIdx.x;
     const int C = (int)min(n_cand[f], (unsigned)kCandMax);
 
-    for (int i = tid; i < C; i += 256) sIn[i] = cands[(size_t)f * kCandMax + i];
-    for (int i = tid; i < kCandMax * (kCandMax / 32); i += 256) (&nearBits[0][0])[i] = 0u;
-    for (int i = tid; i < kCandMax; i += 256) removed[i] = 0;
+    for (int i = tid; i < C; i += AT) sIn[i] = cands[(size_t)f * kCandMax + i];
+    for (int i = tid; i < kCandMax; i += AT) removed[i] = 0;
+    if (tid == 0) sNPair = 0;
     __syncthreads();
     // rank sort by ordkey (unique inside a frame): OpenCV order = scale ascending, reverse discovery
-    for (int i = tid; i < C; i += 256) {
+    for (int i = tid; i < C; i += AT) {
         unsigned k = sIn[i].ordkey;
         int rank = 0;
         for (int j = 0; j < C; j++) rank += sIn[j].ordkey < k;
@@ -440,8 +445,9 @@ __global__ __launch_bounds__(256) void k_assemble(DetectCfg cfg, Counters* ctr, 
         sC[rank] = c;
     }
     __syncthreads();
-    // _filterTooCloseCandidates, part 1: near pairs (i < j)
-    for (int p = tid; p < C * C; p += 256) {
+    // _filterTooCloseCandidates, part 1: near pairs (i < j).  A cheap exact pre-test skips far pairs: the mean
+    // squared corner distance of any cyclic matching is >= the squared distance between the corner centroids.
+    for (int p = tid; p < C * C; p += AT) {
         int i = p / C, j = p - i * C;
         if (j > i) {
             const CandRec& a = sC[i];
@@ -449,40 +455,52 @@ __global__ __launch_bounds__(256) void k_assemble(DetectCfg cfg, Counters* ctr, 
             int minimumPerimeter = (int)min(a.n, bq.n);
             double minMarkerDistancePixels = (double)minimumPerimeter * cfg.min_marker_dist_rate;
             double thr = minMarkerDistancePixels * minMarkerDistancePixels;
+            int sax = a.x[0] + a.x[1] + a.x[2] + a.x[3], say = a.y[0] + a.y[1] + a.y[2] + a.y[3];
+            int sbx = bq.x[0] + bq.x[1] + bq.x[2] + bq.x[3], sby = bq.y[0] + bq.y[1] + bq.y[2] + bq.y[3];
+            double cdx = (double)(sax - sbx) * 0.25, cdy = (double)(say - sby) * 0.25;
             bool near = false;
-            for (int fc = 0; fc < 4 && !near; fc++) {
-                double distSq = 0;
-                for (int c = 0; c < 4; c++) {
-                    int modC = (c + fc) & 3;
-                    double ddx = (double)(a.x[modC] - bq.x[c]), ddy = (double)(a.y[modC] - bq.y[c]);
-                    distSq += ddx * ddx + ddy * ddy;
+            if (cdx * cdx + cdy * cdy < thr + 1.0) {
+                for (int fc = 0; fc < 4 && !near; fc++) {
+                    double distSq = 0;
+                    for (int c = 0; c < 4; c++) {
+                        int modC = (c + fc) & 3;
+                        double ddx = (double)(a.x[modC] - bq.x[c]), ddy = (double)(a.y[modC] - bq.y[c]);
+                        distSq += ddx * ddx + ddy * ddy;
+                    }
+                    distSq /= 4.;
+                    if (distSq < thr) near = true;
                 }
-                distSq /= 4.;
-                if (distSq < thr) near = true;
             }
-            if (near) atomicOr(&nearBits[i][j >> 5], 1u << (j & 31));
+            if (near) {
+                unsigned k = atomicAdd(&sNPair, 1u);
+                if (k < (unsigned)kPairMax) sPair[k] = ((unsigned)i << 16) | (unsigned)j;
+                else atomicOr(&ctr->overflow, (unsigned)kOvfCands);
+            }
         }
+    }
+    __syncthreads();
+    const int P = (int)min(sNPair, (unsigned)kPairMax);
+    for (int i = tid; i < P; i += AT) {
+        unsigned k = sPair[i];
+        int rank = 0;
+        for (int j = 0; j < P; j++) rank += sPair[j] < k;
+        sPairSorted[rank] = k;
     }
     __syncthreads();
     // part 2: sequential marking in pair order (depends on earlier removals)
     if (tid == 0) {
-        for (int i = 0; i < C; i++)
-            for (int wd = 0; wd < (C + 31) / 32; wd++) {
-                unsigned bits = nearBits[i][wd];
-                while (bits) {
-                    int j = wd * 32 + (__ffs((int)bits) - 1);
-                    bits &= bits - 1;
-                    if (removed[i] || removed[j]) continue;
-                    if (sC[i].n > sC[j].n) removed[j] = 1;
-                    else removed[i] = 1;
-                }
-            }
+        for (int q = 0; q < P; q++) {
+            int i = (int)(sPairSorted[q] >> 16), j = (int)(sPairSorted[q] & 0xFFFFu);
+            if (removed[i] || removed[j]) continue;
+            if (sC[i].n > sC[j].n) removed[j] = 1;
+            else removed[i] = 1;
+        }
         int k = 0;
         for (int i = 0; i < C; i++) { outPos[i] = removed[i] ? -1 : k; k += removed[i] ? 0 : 1; }
         n_final[f] = (unsigned)k;
     }
     __syncthreads();
-    for (int i = tid; i < C; i += 256) {
+    for (int i = tid; i < C; i += AT) {
         int k = outPos[i];
         if (k >= 0) {
             FinalCand fc;
@@ -721,7 +739,7 @@ void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, Counters* ct
 }
 void launch_assemble(hipStream_t st, int nframes, const DetectCfg& cfg, Counters* ctr, const CandRec* cands,
                      const unsigned* n_cand, FinalCand* finals, unsigned* n_final, IdentWork* work) {
-    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(256), 0, st, cfg, ctr, cands, n_cand, finals, n_final, work);
+    hipLaunchKernelGGL(k_assemble, dim3(nframes), dim3(AT), 0, st, cfg, ctr, cands, n_cand, finals, n_final, work);
 }
 void launch_identify(hipStream_t st, int nwaves, const DetectCfg& cfg, Counters* ctr, const uint8_t* gray,
                      FinalCand* finals, const IdentWork* work, const unsigned long long* dict_codes) {
