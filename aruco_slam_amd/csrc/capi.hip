@@ -43,10 +43,15 @@ struct aslam_ctx {
     uint8_t* d_in = nullptr;
     uint8_t* d_gray = nullptr;
     uint8_t* d_nbr = nullptr;
-    unsigned long long* d_starts = nullptr;
+    unsigned* d_starts = nullptr;          // per frame: cap_starts entries
+    unsigned* d_nstarts = nullptr;
     Counters* d_ctr = nullptr;
-    ContourRec* d_contours = nullptr;
-    unsigned* d_points = nullptr;
+    ContourRec* d_contours = nullptr;      // per frame: cap_contours records
+    unsigned* d_ncontours = nullptr;
+    unsigned* d_points = nullptr;          // per frame: cap_points packed (x, y)
+    unsigned* d_npoints = nullptr;
+    unsigned* d_pre_trace = nullptr;       // ticket ranges of the work-queue kernels
+    unsigned* d_pre_quads = nullptr;
     CandRec* d_cands = nullptr;
     unsigned* d_ncand = nullptr;
     FinalCand* d_finals = nullptr;
@@ -169,9 +174,9 @@ int configure_frames(aslam_ctx* c, int rows, int cols, int channels) {
     g.max_corr = (int)((double)c->dict_maxcorr * 0.6);
     g.n_dict = c->dict_n;
     g.min_otsu_std = 5.0;
-    g.cap_starts = c->init.cap_starts_per_frame * (unsigned)c->max_batch;
-    g.cap_contours = c->init.cap_contours_per_frame * (unsigned)c->max_batch;
-    g.cap_points = c->init.cap_points_per_frame * (unsigned)c->max_batch;
+    g.cap_starts = c->init.cap_starts_per_frame;
+    g.cap_contours = c->init.cap_contours_per_frame;
+    g.cap_points = c->init.cap_points_per_frame;
     return ASLAM_OK;
 }
 
@@ -187,35 +192,49 @@ int run_detect(aslam_ctx* c, int first, int count) {
     hipStream_t st = c->stream;
     const DetectCfg& g = c->cfg;
     const size_t frame_px = (size_t)g.rows * g.cols;
-    HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
-    HIP_TRY(c, hipMemsetAsync(c->d_ncand + first, 0, sizeof(unsigned) * count, st));
-    // per-frame arrays are indexed by slot: pass base pointers offset to `first`
-    prof_begin(c, P_THRESH);
-    launch_threshold(st, c->d_in + (size_t)first * c->in_frame_bytes, c->channels, c->in_frame_bytes,
-                     (size_t)g.cols * c->channels, count, c->d_gray + (size_t)first * frame_px,
-                     c->d_nbr + (size_t)first * kScales * g.rows * g.pitch, g, c->d_starts, c->d_ctr);
-    prof_end(c);
-    prof_begin(c, P_TRACE);
-    launch_trace(st, c->nwaves, c->d_nbr + (size_t)first * kScales * g.rows * g.pitch, g, c->d_starts, c->d_ctr, c->d_contours, c->d_points);
-    prof_end(c);
-    prof_begin(c, P_QUADS);
-    launch_quads(st, c->nwaves, g, c->d_ctr, c->d_contours, c->d_points, c->d_cands + (size_t)first * kCandMax, c->d_ncand + first);
-    prof_end(c);
-    prof_begin(c, P_ASSEMBLE);
-    launch_assemble(st, count, g, c->d_ctr, c->d_cands + (size_t)first * kCandMax, c->d_ncand + first,
-                    c->d_finals + (size_t)first * kCandMax, c->d_nfinal + first, c->d_work);
-    prof_end(c);
-    prof_begin(c, P_IDENTIFY);
-    launch_identify(st, c->nwaves, g, c->d_ctr, c->d_gray + (size_t)first * frame_px, c->d_finals + (size_t)first * kCandMax,
-                    c->d_work, c->d_dict);
-    prof_end(c);
-    prof_begin(c, P_POSE);
-    launch_pose(st, count, c->d_finals + (size_t)first * kCandMax, c->d_nfinal + first, c->d_markers + (size_t)first * kMarkerMax,
-                c->d_nmarkers + first, c->d_obs + (size_t)first * kMarkerMax, c->cam, c->sp, c->d_ctr);
-    prof_end(c);
-    HIP_TRY(c, hipGetLastError());
+    const bool alias_gray = c->channels == 1;              // staged gray frames are tight: the detector reads them in place
     c->last_first = first;
     c->last_count = count;
+    for (int f0 = first; f0 < first + count; f0 += max_frames_per_call()) {
+        const int nf = std::min(max_frames_per_call(), first + count - f0);
+        HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned), st));       // queue heads and work count; the overflow mask is sticky
+        HIP_TRY(c, hipMemsetAsync(c->d_nstarts + f0, 0, sizeof(unsigned) * nf, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_ncontours + f0, 0, sizeof(unsigned) * nf, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_npoints + f0, 0, sizeof(unsigned) * nf, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_ncand + f0, 0, sizeof(unsigned) * nf, st));
+        const uint8_t* in = c->d_in + (size_t)f0 * c->in_frame_bytes;
+        uint8_t* nbr = c->d_nbr + (size_t)f0 * kScales * g.rows * g.pitch;
+        const uint8_t* gray = alias_gray ? in : c->d_gray + (size_t)f0 * frame_px;
+        unsigned* starts = c->d_starts + (size_t)f0 * g.cap_starts;
+        ContourRec* contours = c->d_contours + (size_t)f0 * g.cap_contours;
+        unsigned* points = c->d_points + (size_t)f0 * g.cap_points;
+        prof_begin(c, P_THRESH);
+        launch_threshold(st, in, c->channels, c->in_frame_bytes, (size_t)g.cols * c->channels, nf,
+                         alias_gray ? nullptr : c->d_gray + (size_t)f0 * frame_px, nbr, g, starts, c->d_nstarts + f0, c->d_ctr);
+        prof_end(c);
+        prof_begin(c, P_TRACE);
+        launch_prefix(st, nf, c->d_nstarts + f0, g.cap_starts, 64u, c->d_pre_trace);
+        launch_trace(st, c->nwaves, nbr, g, nf, starts, c->d_nstarts + f0, c->d_pre_trace, c->d_ctr, contours, c->d_ncontours + f0,
+                     points, c->d_npoints + f0);
+        prof_end(c);
+        prof_begin(c, P_QUADS);
+        launch_prefix(st, nf, c->d_ncontours + f0, g.cap_contours, 1u, c->d_pre_quads);
+        launch_quads(st, c->nwaves, g, nf, c->d_ctr, contours, c->d_ncontours + f0, c->d_pre_quads, points,
+                     c->d_cands + (size_t)f0 * kCandMax, c->d_ncand + f0);
+        prof_end(c);
+        prof_begin(c, P_ASSEMBLE);
+        launch_assemble(st, nf, g, c->d_ctr, c->d_cands + (size_t)f0 * kCandMax, c->d_ncand + f0,
+                        c->d_finals + (size_t)f0 * kCandMax, c->d_nfinal + f0, c->d_work);
+        prof_end(c);
+        prof_begin(c, P_IDENTIFY);
+        launch_identify(st, c->nwaves, g, c->d_ctr, gray, c->d_finals + (size_t)f0 * kCandMax, c->d_work, c->d_dict);
+        prof_end(c);
+        prof_begin(c, P_POSE);
+        launch_pose(st, nf, c->d_finals + (size_t)f0 * kCandMax, c->d_nfinal + f0, c->d_markers + (size_t)f0 * kMarkerMax,
+                    c->d_nmarkers + f0, c->d_obs + (size_t)f0 * kMarkerMax, c->cam, c->sp, c->d_ctr);
+        prof_end(c);
+    }
+    HIP_TRY(c, hipGetLastError());
     return ASLAM_OK;
 }
 
@@ -246,6 +265,8 @@ int sync_and_check(aslam_ctx* c) {
     Counters h{};
     HIP_TRY(c, hipMemcpy(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
     if (h.overflow) {
+        unsigned zero = 0;
+        hipMemcpy(&c->d_ctr->overflow, &zero, sizeof(unsigned), hipMemcpyHostToDevice);
         char buf[256];
         snprintf(buf, sizeof(buf), "device list overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 candidates, 16 markers, 32 landmarks)", h.overflow);
         return fail(c, ASLAM_E_CAPACITY, buf);
@@ -282,8 +303,8 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     if (hipSetDevice(init->device_id) != hipSuccess) return ASLAM_E_NO_DEVICE;
     aslam_ctx* c = new aslam_ctx();
     c->init = *init;
-    if (c->init.cap_starts_per_frame == 0) c->init.cap_starts_per_frame = 1u << 17;
-    if (c->init.cap_contours_per_frame == 0) c->init.cap_contours_per_frame = 1u << 13;
+    if (c->init.cap_starts_per_frame == 0) c->init.cap_starts_per_frame = 1u << 16;
+    if (c->init.cap_contours_per_frame == 0) c->init.cap_contours_per_frame = 1u << 12;
     if (c->init.cap_points_per_frame == 0) c->init.cap_points_per_frame = 1u << 19;
     c->max_batch = init->max_batch;
     c->nwaves = init->persistent_waves > 0 ? init->persistent_waves : 2048;
@@ -300,9 +321,14 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && dalloc(&c->d_gray, px * B) == hipSuccess;
     ok = ok && dalloc(&c->d_nbr, (size_t)kScales * init->max_rows * pitch * B) == hipSuccess;
     ok = ok && dalloc(&c->d_starts, (size_t)c->init.cap_starts_per_frame * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_nstarts, B) == hipSuccess;
     ok = ok && dalloc(&c->d_ctr, 1) == hipSuccess;
     ok = ok && dalloc(&c->d_contours, (size_t)c->init.cap_contours_per_frame * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_ncontours, B) == hipSuccess;
     ok = ok && dalloc(&c->d_points, (size_t)c->init.cap_points_per_frame * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_npoints, B) == hipSuccess;
+    ok = ok && dalloc(&c->d_pre_trace, (size_t)max_frames_per_call() + 1) == hipSuccess;
+    ok = ok && dalloc(&c->d_pre_quads, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_cands, (size_t)kCandMax * B) == hipSuccess;
     ok = ok && dalloc(&c->d_ncand, B) == hipSuccess;
     ok = ok && dalloc(&c->d_finals, (size_t)kCandMax * B) == hipSuccess;
@@ -318,6 +344,9 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && dalloc(&c->d_dict, codes.size()) == hipSuccess;
     ok = ok && hipMemcpy(c->d_dict, codes.data(), codes.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemset(c->d_ctr, 0, sizeof(Counters)) == hipSuccess;
+    ok = ok && hipMemset(c->d_nstarts, 0, sizeof(unsigned) * B) == hipSuccess;
+    ok = ok && hipMemset(c->d_ncontours, 0, sizeof(unsigned) * B) == hipSuccess;
+    ok = ok && hipMemset(c->d_npoints, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_nmarkers, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_nfinal, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_ncand, 0, sizeof(unsigned) * B) == hipSuccess;
@@ -333,6 +362,7 @@ void aslam_destroy(aslam_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     prof_collect(c);
     hipFree(c->d_in); hipFree(c->d_gray); hipFree(c->d_nbr); hipFree(c->d_starts); hipFree(c->d_ctr);
+    hipFree(c->d_nstarts); hipFree(c->d_ncontours); hipFree(c->d_npoints); hipFree(c->d_pre_trace); hipFree(c->d_pre_quads);
     hipFree(c->d_contours); hipFree(c->d_points); hipFree(c->d_cands); hipFree(c->d_ncand); hipFree(c->d_finals);
     hipFree(c->d_nfinal); hipFree(c->d_work); hipFree(c->d_dict); hipFree(c->d_markers); hipFree(c->d_nmarkers);
     hipFree(c->d_obs); hipFree(c->d_enc); hipFree(c->d_synth);
@@ -601,19 +631,20 @@ int aslam_debug_get_nbr(aslam_ctx* c, int slot, int scale, uint8_t* out) {
     return ASLAM_OK;
 }
 
-// contours of one (slot, scale) of the LAST aslam_run_staged call, sorted into OpenCV order (descending key)
+// contours of one (slot, scale) of the last detection that covered the slot, sorted into OpenCV order (descending key)
 int aslam_debug_get_contours(aslam_ctx* c, int slot, int scale, int max_contours, long long max_points, int* n_contours,
                              int* sizes, int* keys, int* points_xy, long long* n_points) {
     if (!c || !n_contours) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    int rr = check_slot_range(c, slot, 1);
+    if (rr) return rr;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    Counters h{};
-    HIP_TRY(c, hipMemcpy(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
-    unsigned nc = std::min(h.n_contours, c->cfg.cap_contours);
+    unsigned nc = 0;
+    HIP_TRY(c, hipMemcpy(&nc, c->d_ncontours + slot, sizeof(unsigned), hipMemcpyDeviceToHost));
+    nc = std::min(nc, c->cfg.cap_contours);
     std::vector<ContourRec> recs(nc);
-    if (nc) HIP_TRY(c, hipMemcpy(recs.data(), c->d_contours, nc * sizeof(ContourRec), hipMemcpyDeviceToHost));
+    if (nc) HIP_TRY(c, hipMemcpy(recs.data(), c->d_contours + (size_t)slot * c->cfg.cap_contours, nc * sizeof(ContourRec), hipMemcpyDeviceToHost));
     std::vector<ContourRec> sel;
-    const unsigned frame_rel = (unsigned)(slot - c->last_first);
-    for (auto& r : recs) if (r.frame == frame_rel && r.scale == (unsigned)scale) sel.push_back(r);
+    for (auto& r : recs) if (r.scale == (unsigned)scale) sel.push_back(r);
     std::sort(sel.begin(), sel.end(), [](const ContourRec& a, const ContourRec& b) { return a.key > b.key; });
     long long tot = 0;
     int n = 0;
@@ -621,7 +652,7 @@ int aslam_debug_get_contours(aslam_ctx* c, int slot, int scale, int max_contours
     for (auto& r : sel) {
         if (n >= max_contours || tot + (long long)r.n > max_points) return fail(c, ASLAM_E_CAPACITY, "debug buffer too small");
         pts.resize(r.n);
-        if (r.n) HIP_TRY(c, hipMemcpy(pts.data(), c->d_points + r.off, r.n * sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (r.n) HIP_TRY(c, hipMemcpy(pts.data(), c->d_points + (size_t)slot * c->cfg.cap_points + r.off, r.n * sizeof(unsigned), hipMemcpyDeviceToHost));
         if (sizes) sizes[n] = (int)r.n;
         if (keys) keys[n] = (int)r.key;
         if (points_xy)

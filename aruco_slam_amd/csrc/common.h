@@ -36,11 +36,11 @@ struct DetectCfg {
     int max_corr;                     // int(maxCorrectionBits * errorCorrectionRate)
     int n_dict;                       // markers in the dictionary
     double min_otsu_std;              // 5.0
-    unsigned cap_starts, cap_contours, cap_points;
+    unsigned cap_starts, cap_contours, cap_points;   // per frame
 };
 
-struct Counters {
-    unsigned n_starts, q_trace, n_contours, q_quads, n_points, n_ident, q_ident, overflow;
+struct Counters {                 // per-call scalars (work-queue heads, overflow mask); list sizes live in per-frame arrays
+    unsigned q_trace, q_quads, n_ident, q_ident, overflow, pad[3];
 };
 
 struct ContourRec {

@@ -5,14 +5,17 @@
 namespace aslam {
 
 void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t frame_stride, size_t row_step, int nframes,
-                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned long long* starts, Counters* ctr);
-void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, const unsigned long long* starts,
-                  Counters* ctr, ContourRec* contours, unsigned* points);
-void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, Counters* ctr, const ContourRec* contours,
-                  const unsigned* points, CandRec* cands, unsigned* n_cand);
+                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, Counters* ctr);
+void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre);
+void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
+                  const unsigned* n_starts, const unsigned* pre, Counters* ctr, ContourRec* contours, unsigned* n_contours,
+                  unsigned* points, unsigned* n_points);
+void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, int nframes, Counters* ctr, const ContourRec* contours,
+                  const unsigned* n_contours, const unsigned* pre, const unsigned* points, CandRec* cands, unsigned* n_cand);
 void launch_assemble(hipStream_t st, int nframes, const DetectCfg& cfg, Counters* ctr, const CandRec* cands,
                      const unsigned* n_cand, FinalCand* finals, unsigned* n_final, IdentWork* work);
 void launch_identify(hipStream_t st, int nwaves, const DetectCfg& cfg, Counters* ctr, const uint8_t* gray,
                      FinalCand* finals, const IdentWork* work, const unsigned long long* dict_codes);
+int max_frames_per_call();
 
 } // namespace aslam

@@ -30,56 +30,107 @@ namespace aslam {
 constexpr int TW = 64, TH = 32, HALO = 12;
 constexpr int LW = TW + 2 * HALO;   // 88
 constexpr int LH = TH + 2 * HALO;   // 56
+constexpr int kBlockStarts = 1024;  // start candidates staged per tile before one reservation in the frame's list
+
+template <int R> __device__ __forceinline__ unsigned box_mean(const unsigned (*I)[LW + 1], int ly, int lx) {
+    constexpr unsigned k2 = (2 * R + 1) * (2 * R + 1);
+    unsigned sum = I[ly + R + 1][lx + R + 1] - I[ly - R][lx + R + 1] - I[ly + R + 1][lx - R] + I[ly - R][lx - R];
+    return (2u * sum + k2) / (2u * k2);       // round-to-nearest; k2 is odd so a tie cannot occur (division by a constant)
+}
 
 __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ in, int channels, size_t in_frame_stride,
                                                    size_t in_row_step, uint8_t* __restrict__ gray_out,
                                                    uint8_t* __restrict__ nbr, DetectCfg cfg,
-                                                   unsigned long long* __restrict__ starts, Counters* ctr) {
+                                                   unsigned* __restrict__ starts, unsigned* __restrict__ n_starts,
+                                                   Counters* ctr) {
     __shared__ uint8_t g[LH][LW];
     __shared__ unsigned I[LH + 1][LW + 1];
     __shared__ uint8_t bin[TH + 2][TW + 2];
+    __shared__ unsigned sStart[kBlockStarts];      // x | y << 12 | scale << 24 | type << 26
+    __shared__ unsigned sNStart, sBase;
 
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int rows = cfg.rows, cols = cfg.cols;
     const uint8_t* src = in + (size_t)b * in_frame_stride;
+    if (tid == 0) sNStart = 0;
 
     // 1. gray tile with replicated border (BORDER_REPLICATE of the box filter)
-    for (int i = tid; i < LH * LW; i += 256) {
-        int ly = i / LW, lx = i - ly * LW;
-        int gx = min(max(x0 + lx - HALO, 0), cols - 1);
-        int gy = min(max(y0 + ly - HALO, 0), rows - 1);
-        const uint8_t* p = src + (size_t)gy * in_row_step + (size_t)gx * channels;
-        unsigned v;
-        if (channels == 3) v = (p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14;
-        else v = p[0];
-        g[ly][lx] = (uint8_t)v;
+    if (channels == 1 && (in_row_step & 3) == 0 && ((size_t)src & 3) == 0) {
+        // 4 pixels per load where the dword lies inside the row; LW = 88 = 22 dwords per tile row
+        for (int i = tid; i < LH * (LW / 4); i += 256) {
+            int ly = i / (LW / 4), q = i - ly * (LW / 4);
+            int gy = min(max(y0 + ly - HALO, 0), rows - 1);
+            int gx = x0 + 4 * q - HALO;
+            const uint8_t* rowp = src + (size_t)gy * in_row_step;
+            unsigned v;
+            if (gx >= 0 && gx + 3 < cols) {
+                v = *reinterpret_cast<const unsigned*>(rowp + gx);
+            } else {
+                v = 0;
+                for (int k = 0; k < 4; k++) v |= (unsigned)rowp[min(max(gx + k, 0), cols - 1)] << (8 * k);
+            }
+            *reinterpret_cast<unsigned*>(&g[ly][4 * q]) = v;
+        }
+    } else {
+        for (int i = tid; i < LH * LW; i += 256) {
+            int ly = i / LW, lx = i - ly * LW;
+            int gx = min(max(x0 + lx - HALO, 0), cols - 1);
+            int gy = min(max(y0 + ly - HALO, 0), rows - 1);
+            const uint8_t* p = src + (size_t)gy * in_row_step + (size_t)gx * channels;
+            unsigned v;
+            if (channels == 3) v = (p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14;
+            else v = p[0];
+            g[ly][lx] = (uint8_t)v;
+        }
     }
     __syncthreads();
 
-    // tight gray plane for the bit-extraction stage
-    for (int i = tid; i < TH * TW; i += 256) {
-        int ty = i / TW, tx = i - ty * TW;
-        int gx = x0 + tx, gy = y0 + ty;
-        if (gx < cols && gy < rows) gray_out[((size_t)b * rows + gy) * cols + gx] = g[ty + HALO][tx + HALO];
+    // tight gray plane for the bit-extraction stage (skipped when the input already is one)
+    if (gray_out != nullptr) {
+        for (int i = tid; i < TH * TW; i += 256) {
+            int ty = i / TW, tx = i - ty * TW;
+            int gx = x0 + tx, gy = y0 + ty;
+            if (gx < cols && gy < rows) gray_out[((size_t)b * rows + gy) * cols + gx] = g[ty + HALO][tx + HALO];
+        }
     }
 
-    // 2. integral image I[y+1][x+1] = sum_{y'<=y, x'<=x} g
-    if (tid < LH) {
+    // 2. integral image I[y+1][x+1] = sum_{y'<=y, x'<=x} g : rows by 4 threads each (22 px), then columns by 2 threads each
+    if (tid < LH * 4) {
+        const int r = tid >> 2, q = tid & 3;
         unsigned s = 0;
-        I[tid + 1][0] = 0;
-        for (int lx = 0; lx < LW; lx++) { s += g[tid][lx]; I[tid + 1][lx + 1] = s; }
+        for (int k = 0; k < LW / 4; k++) { s += g[r][q * (LW / 4) + k]; I[r + 1][q * (LW / 4) + k + 1] = s; }
     }
-    if (tid >= 64 && tid < 64 + LW + 1) I[0][tid - 64] = 0;
+    if (tid < LW + 1) I[0][tid] = 0;
+    if (tid < LH) I[tid + 1][0] = 0;
     __syncthreads();
-    if (tid < LW) {
+    {
+        const int r = tid >> 2, q = tid & 3;
+        unsigned add = 0;
+        if (tid < LH * 4)
+            for (int qq = 0; qq < q; qq++) add += I[r + 1][(qq + 1) * (LW / 4)];     // totals of the preceding quarters (still local sums)
+        __syncthreads();
+        if (tid < LH * 4 && q > 0)
+            for (int k = 0; k < LW / 4; k++) I[r + 1][q * (LW / 4) + k + 1] += add;
+    }
+    __syncthreads();
+    if (tid < LW * 2) {
+        const int c = tid >> 1, h = tid & 1;
         unsigned s = 0;
-        for (int ly = 0; ly < LH; ly++) { s += I[ly + 1][tid + 1]; I[ly + 1][tid + 1] = s; }
+        for (int k = 0; k < LH / 2; k++) { s += I[h * (LH / 2) + k + 1][c + 1]; I[h * (LH / 2) + k + 1][c + 1] = s; }
+    }
+    __syncthreads();
+    if (tid < LW * 2) {
+        const int c = tid >> 1, h = tid & 1;
+        if (h == 1) {
+            const unsigned add = I[LH / 2][c + 1];
+            for (int k = 0; k < LH / 2; k++) I[LH / 2 + k + 1][c + 1] += add;
+        }
     }
     __syncthreads();
 
-    // 3. three thresholds for the tile plus a 1-px ring (needed by the neighbour masks)
+    // 3. three thresholds (windows 3 / 13 / 23) for the tile plus a 1-px ring (needed by the neighbour masks)
     for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
         int by = i / (TW + 2), bx = i - by * (TW + 2);
         int gx = x0 + bx - 1, gy = y0 + by - 1;
@@ -87,21 +138,16 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         if (gx >= 0 && gx < cols && gy >= 0 && gy < rows) {
             int lx = bx - 1 + HALO, ly = by - 1 + HALO;
             int v = g[ly][lx];
-#pragma unroll
-            for (int s = 0; s < kScales; s++) {
-                int r = cfg.win_r[s];
-                int k2 = (2 * r + 1) * (2 * r + 1);
-                unsigned sum = I[ly + r + 1][lx + r + 1] - I[ly - r][lx + r + 1] - I[ly + r + 1][lx - r] + I[ly - r][lx - r];
-                int mean = (int)((2u * sum + (unsigned)k2) / (2u * (unsigned)k2));   // round-to-nearest, never a tie
-                if (v - mean <= -cfg.thresh_c) bits |= 1u << s;
-            }
+            if (v - (int)box_mean<1>(I, ly, lx) <= -cfg.thresh_c) bits |= 1u;
+            if (v - (int)box_mean<6>(I, ly, lx) <= -cfg.thresh_c) bits |= 2u;
+            if (v - (int)box_mean<11>(I, ly, lx) <= -cfg.thresh_c) bits |= 4u;
         }
         bin[by][bx] = (uint8_t)bits;
     }
     __syncthreads();
 
     // 4. neighbour masks (bit d = neighbour in direction d is foreground; 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE)
-    //    and border start candidates
+    //    and border start candidates (staged in LDS, one reservation per tile in the frame's list)
     for (int u = tid; u < TH * TW / 4; u += 256) {
         int ty = u / (TW / 4), tx4 = (u - ty * (TW / 4)) * 4;
         int gy = y0 + ty;
@@ -123,9 +169,15 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                     bool outer = fg && m != 0 && (m & 0x1Eu) == 0;
                     bool hole = !fg && (m & 0x14u) == 0x14u;
                     if (outer || hole) {
-                        unsigned k = atomicAdd(&ctr->n_starts, 1u);
-                        if (k < cfg.cap_starts) starts[k] = pack_start((unsigned)gx, (unsigned)gy, (unsigned)s, hole ? 1u : 0u, (unsigned)b);
-                        else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
+                        unsigned k = atomicAdd(&sNStart, 1u);
+                        unsigned ent = (unsigned)gx | ((unsigned)gy << 12) | ((unsigned)s << 24) | ((hole ? 1u : 0u) << 26);
+                        if (k < (unsigned)kBlockStarts) {
+                            sStart[k] = ent;
+                        } else {                                  // pathological tile (> 1024 candidates): go to the list directly
+                            unsigned kk = atomicAdd(&n_starts[b], 1u);
+                            if (kk < cfg.cap_starts) starts[(size_t)b * cfg.cap_starts + kk] = ent;
+                            else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
+                        }
                     }
                 }
             }
@@ -138,7 +190,56 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
             }
         }
     }
+    __syncthreads();
+    const unsigned ns = min(sNStart, (unsigned)kBlockStarts);
+    if (tid == 0 && ns > 0) sBase = atomicAdd(&n_starts[b], ns);
+    __syncthreads();
+    for (unsigned i = tid; i < ns; i += 256) {
+        unsigned k = sBase + i;
+        if (k < cfg.cap_starts) starts[(size_t)b * cfg.cap_starts + k] = sStart[i];
+        else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
+    }
 }
+
+// ------------------------------------------------------------------------------------------------
+// k_prefix : per-frame work counts -> ticket ranges of the two work-queue kernels (one workgroup)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prefix(int nframes, const unsigned* __restrict__ counts, unsigned cap, unsigned per_ticket,
+                                                unsigned* __restrict__ pre /* nframes + 1 */) {
+    __shared__ unsigned sPart[256];
+    const int tid = threadIdx.x;
+    const int per = (nframes + 255) / 256;
+    unsigned s = 0;
+    for (int k = 0; k < per; k++) {
+        int f = tid * per + k;
+        if (f < nframes) s += (min(counts[f], cap) + per_ticket - 1) / per_ticket;
+    }
+    sPart[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned acc = 0;
+        for (int i = 0; i < 256; i++) { unsigned v = sPart[i]; sPart[i] = acc; acc += v; }
+        pre[nframes] = acc;
+    }
+    __syncthreads();
+    unsigned acc = sPart[tid];
+    for (int k = 0; k < per; k++) {
+        int f = tid * per + k;
+        if (f < nframes) { pre[f] = acc; acc += (min(counts[f], cap) + per_ticket - 1) / per_ticket; }
+    }
+}
+
+// ticket -> frame: largest f with pre[f] <= ticket (pre is non-decreasing, staged in LDS by the caller)
+__device__ __forceinline__ int ticket_frame(const unsigned* sPre, int nframes, unsigned ticket) {
+    int lo = 0, hi = nframes;                 // invariant: pre[lo] <= ticket < pre[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (sPre[mid] <= ticket) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+constexpr int kMaxFramesPerCall = 1024;
 
 // ------------------------------------------------------------------------------------------------
 // k_trace
@@ -163,22 +264,29 @@ __device__ __forceinline__ void walk_step(Walk& w, unsigned m) {
     w.s = (s2 + 4) & 7;
 }
 
-__global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, DetectCfg cfg,
-                                              const unsigned long long* __restrict__ starts, Counters* ctr,
-                                              ContourRec* __restrict__ contours, unsigned* __restrict__ points) {
+__global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, DetectCfg cfg, int nframes,
+                                              const unsigned* __restrict__ starts, const unsigned* __restrict__ n_starts,
+                                              const unsigned* __restrict__ pre, Counters* ctr,
+                                              ContourRec* __restrict__ contours, unsigned* __restrict__ n_contours,
+                                              unsigned* __restrict__ points, unsigned* __restrict__ n_points) {
+    __shared__ unsigned sPre[kMaxFramesPerCall + 1];
     const int lane = threadIdx.x & 63;
-    const unsigned n_starts = min(ctr->n_starts, cfg.cap_starts);
+    for (int i = lane; i <= nframes; i += 64) sPre[i] = pre[i];
+    __syncthreads();
+    const unsigned total = sPre[nframes];
     const int pitch = cfg.pitch, cols = cfg.cols;
     for (;;) {
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->q_trace, 64u);
-        base = __shfl(base, 0);
-        if (base >= n_starts) break;
-        unsigned idx = base + lane;
-        if (idx < n_starts) {
-            unsigned long long e = starts[idx];
+        unsigned ticket = 0;
+        if (lane == 0) ticket = atomicAdd(&ctr->q_trace, 1u);
+        ticket = __shfl(ticket, 0);
+        if (ticket >= total) break;
+        const int f = ticket_frame(sPre, nframes, ticket);
+        const unsigned nst = min(n_starts[f], cfg.cap_starts);
+        const unsigned idx = (ticket - sPre[f]) * 64u + lane;
+        if (idx < nst) {
+            unsigned e = starts[(size_t)f * cfg.cap_starts + idx];
             int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
-            unsigned sc = (unsigned)((e >> 24) & 3u), type = (unsigned)((e >> 26) & 1u), f = (unsigned)(e >> 32);
+            unsigned sc = (e >> 24) & 3u, type = (e >> 26) & 1u;
             const uint8_t* plane = nbr + ((size_t)f * kScales + sc) * cfg.rows * pitch;
             const int key0 = y * cols + x;
             if (type) x -= 1;                                  // hole border starts on the pixel left of the hole
@@ -211,19 +319,20 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                 if (n < cfg.min_perim || n > cfg.max_perim) alive = false;
             }
             if (alive) {
-                unsigned ci = atomicAdd(&ctr->n_contours, 1u);
-                unsigned off = atomicAdd(&ctr->n_points, (unsigned)n);
+                unsigned ci = atomicAdd(&n_contours[f], 1u);
+                unsigned off = atomicAdd(&n_points[f], (unsigned)n);
                 if (ci >= cfg.cap_contours) atomicOr(&ctr->overflow, (unsigned)kOvfContours);
                 else if ((unsigned long long)off + (unsigned)n > cfg.cap_points) {
                     atomicOr(&ctr->overflow, (unsigned)kOvfPoints);
-                    ContourRec rec{f, sc, (unsigned)key0, 0u, 0u, (short)sx, (short)sy, s0};
-                    contours[ci] = rec;
+                    ContourRec rec{(unsigned)f, sc, (unsigned)key0, 0u, 0u, (short)sx, (short)sy, s0};
+                    contours[(size_t)f * cfg.cap_contours + ci] = rec;
                 } else {
-                    ContourRec rec{f, sc, (unsigned)key0, (unsigned)n, off, (short)sx, (short)sy, s0};
-                    contours[ci] = rec;
+                    ContourRec rec{(unsigned)f, sc, (unsigned)key0, (unsigned)n, off, (short)sx, (short)sy, s0};
+                    contours[(size_t)f * cfg.cap_contours + ci] = rec;
+                    unsigned* dst = points + (size_t)f * cfg.cap_points + off;
                     Walk v{sx, sy, s0};
                     for (int i = 0; i < n; i++) {
-                        points[off + i] = ((unsigned)v.x & 0xFFFFu) | ((unsigned)v.y << 16);
+                        dst[i] = ((unsigned)v.x & 0xFFFFu) | ((unsigned)v.y << 16);
                         unsigned m = plane[(size_t)v.y * pitch + v.x];
                         walk_step(v, m);
                     }
@@ -234,7 +343,7 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_quads : approxPolyDP (closed) + quad tests, one lane per contour
+// k_quads : approxPolyDP (closed) + quad tests, one WAVEFRONT per contour
 // ------------------------------------------------------------------------------------------------
 struct IPt { int x, y; };
 __device__ __forceinline__ IPt ld_pt(const unsigned* p, int i) {
@@ -242,10 +351,20 @@ __device__ __forceinline__ IPt ld_pt(const unsigned* p, int i) {
     return IPt{(int)(short)(v & 0xFFFFu), (int)(short)(v >> 16)};
 }
 
+// wave-wide "first maximum": the sequential scans use a strict '>' so the earliest position attaining the maximum wins;
+// distances here are integers held exactly in doubles, so the parallel reduction is bit-identical to the scan.
+__device__ __forceinline__ void wave_first_max(double& d, int& pos) {
+    for (int o = 32; o > 0; o >>= 1) {
+        double od = __shfl_xor(d, o);
+        int op = __shfl_xor(pos, o);
+        if (od > d || (od == d && op < pos)) { d = od; pos = op; }
+    }
+}
+
 // Returns the number of vertices (<= 8) written to out, or -1 when the result cannot have 4 vertices.
 // Early exit rule: every stack slice yields at least one vertex and the final clean-up removes at most
-// floor(count/2) of them, so new_count + stack > 8 can never end at 4.
-__device__ int approx_poly_closed(const unsigned* __restrict__ src, int count, double eps, IPt* out) {
+// floor(count/2) of them, so new_count + stack > 8 can never end at 4.  All lanes run the same control flow.
+__device__ int approx_poly_closed_wave(const unsigned* __restrict__ src, int count, double eps, IPt* out, int lane) {
     struct Range { int start, end; };
     Range stack[10];
     int top = 0;
@@ -258,18 +377,22 @@ __device__ int approx_poly_closed(const unsigned* __restrict__ src, int count, d
 
     right_slice.start = 0;
     for (int it = 0; it < 3; it++) {
-        double max_dist = 0;
-        pos = (pos + right_slice.start) % count;
+        pos = (pos + right_slice.start) % count;             // index of this iteration's start point
         start_pt = ld_pt(src, pos);
-        if (++pos >= count) pos = 0;
-        for (int j = 1; j < count; j++) {
-            pt = ld_pt(src, pos);
-            if (++pos >= count) pos = 0;
+        double best = 0.0;
+        int bestj = 0x7fffffff;
+        for (int j = 1 + lane; j < count; j += 64) {
+            int idx = pos + j;
+            if (idx >= count) idx -= count;
+            pt = ld_pt(src, idx);
             double dx = pt.x - start_pt.x, dy = pt.y - start_pt.y;
             double dist = dx * dx + dy * dy;
-            if (dist > max_dist) { max_dist = dist; right_slice.start = j; }
+            if (dist > best) { best = dist; bestj = j; }
         }
-        le_eps = max_dist <= eps;
+        wave_first_max(best, bestj);
+        if (best > 0.0) right_slice.start = bestj;          // unchanged when no point is farther than 0 (as in the scan)
+        le_eps = best <= eps;
+        // the scan reads `count` points in all, so `pos` is back at the start index
     }
     if (!le_eps) {
         right_slice.end = slice.start = pos % count;
@@ -282,22 +405,27 @@ __device__ int approx_poly_closed(const unsigned* __restrict__ src, int count, d
     while (top > 0) {
         slice = stack[--top];
         end_pt = ld_pt(src, slice.end);
-        pos = slice.start;
-        start_pt = ld_pt(src, pos);
-        if (++pos >= count) pos = 0;
-        if (pos != slice.end) {
-            double max_dist = 0;
+        start_pt = ld_pt(src, slice.start);
+        int first = slice.start + 1;
+        if (first >= count) first = 0;
+        if (first != slice.end) {
+            int len = slice.end - first;                      // interior points first .. end-1 (cyclic)
+            if (len < 0) len += count;
             double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
-            while (pos != slice.end) {
-                pt = ld_pt(src, pos);
-                if (++pos >= count) pos = 0;
+            double best = 0.0;
+            int bestt = 0x7fffffff;
+            for (int t = lane; t < len; t += 64) {
+                int idx = first + t;
+                if (idx >= count) idx -= count;
+                pt = ld_pt(src, idx);
                 double dist = fabs((pt.y - start_pt.y) * dx - (pt.x - start_pt.x) * dy);
-                if (dist > max_dist) { max_dist = dist; right_slice.start = (pos + count - 1) % count; }
+                if (dist > best) { best = dist; bestt = t; }
             }
-            le_eps = max_dist * max_dist <= eps * (dx * dx + dy * dy);
+            wave_first_max(best, bestt);
+            if (best > 0.0) { int idx = first + bestt; if (idx >= count) idx -= count; right_slice.start = idx; }
+            le_eps = best * best <= eps * (dx * dx + dy * dy);
         } else {
             le_eps = true;
-            start_pt = ld_pt(src, slice.start);
         }
         if (le_eps) {
             dst[new_count++] = start_pt;
@@ -354,49 +482,52 @@ __device__ __forceinline__ bool quad_is_convex(const IPt* p) {
     return true;
 }
 
-__global__ __launch_bounds__(64) void k_quads(DetectCfg cfg, Counters* ctr, const ContourRec* __restrict__ contours,
+__global__ __launch_bounds__(64) void k_quads(DetectCfg cfg, int nframes, Counters* ctr, const ContourRec* __restrict__ contours,
+                                              const unsigned* __restrict__ n_contours, const unsigned* __restrict__ pre,
                                               const unsigned* __restrict__ points, CandRec* __restrict__ cands,
                                               unsigned* __restrict__ n_cand) {
+    __shared__ unsigned sPre[kMaxFramesPerCall + 1];
     const int lane = threadIdx.x & 63;
-    const unsigned n_contours = min(ctr->n_contours, cfg.cap_contours);
+    for (int i = lane; i <= nframes; i += 64) sPre[i] = pre[i];
+    __syncthreads();
+    const unsigned total = sPre[nframes];
     for (;;) {
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->q_quads, 64u);
-        base = __shfl(base, 0);
-        if (base >= n_contours) break;
-        unsigned idx = base + lane;
-        if (idx < n_contours) {
-            ContourRec rec = contours[idx];
-            if (rec.n > 0) {
-                IPt q[8];
-                int nv = approx_poly_closed(points + rec.off, (int)rec.n, (double)rec.n * cfg.approx_rate, q);
-                bool ok = nv == 4 && quad_is_convex(q);
-                if (ok) {
-                    int mx = max(cfg.cols, cfg.rows);
-                    double minDistSq = (double)mx * mx;
-                    for (int j = 0; j < 4; j++) {
-                        double ddx = (double)(q[j].x - q[(j + 1) & 3].x), ddy = (double)(q[j].y - q[(j + 1) & 3].y);
-                        double d = ddx * ddx + ddy * ddy;
-                        minDistSq = fmin(minDistSq, d);
-                    }
-                    double minCornerDistancePixels = (double)rec.n * cfg.min_corner_rate;
-                    if (minDistSq < minCornerDistancePixels * minCornerDistancePixels) ok = false;
-                    for (int j = 0; j < 4; j++)
-                        if (q[j].x < cfg.min_border_dist || q[j].y < cfg.min_border_dist ||
-                            q[j].x > cfg.cols - 1 - cfg.min_border_dist || q[j].y > cfg.rows - 1 - cfg.min_border_dist)
-                            ok = false;
+        unsigned ticket = 0;
+        if (lane == 0) ticket = atomicAdd(&ctr->q_quads, 1u);
+        ticket = __shfl(ticket, 0);
+        if (ticket >= total) break;
+        const int f = ticket_frame(sPre, nframes, ticket);
+        const ContourRec rec = contours[(size_t)f * cfg.cap_contours + (ticket - sPre[f])];
+        if (rec.n > 0) {                                       // wave-uniform
+            IPt q[8];
+            int nv = approx_poly_closed_wave(points + (size_t)f * cfg.cap_points + rec.off, (int)rec.n,
+                                             (double)rec.n * cfg.approx_rate, q, lane);
+            bool ok = nv == 4 && quad_is_convex(q);
+            if (ok) {
+                int mx = max(cfg.cols, cfg.rows);
+                double minDistSq = (double)mx * mx;
+                for (int j = 0; j < 4; j++) {
+                    double ddx = (double)(q[j].x - q[(j + 1) & 3].x), ddy = (double)(q[j].y - q[(j + 1) & 3].y);
+                    double d = ddx * ddx + ddy * ddy;
+                    minDistSq = fmin(minDistSq, d);
                 }
-                if (ok) {
-                    unsigned k = atomicAdd(&n_cand[rec.frame], 1u);
-                    if (k < (unsigned)kCandMax) {
-                        CandRec c;
-                        for (int j = 0; j < 4; j++) { c.x[j] = (short)q[j].x; c.y[j] = (short)q[j].y; }
-                        c.n = rec.n;
-                        c.ordkey = rec.scale * (1u << 22) + ((1u << 22) - 1u - rec.key);
-                        cands[(size_t)rec.frame * kCandMax + k] = c;
-                    } else {
-                        atomicOr(&ctr->overflow, (unsigned)kOvfCands);
-                    }
+                double minCornerDistancePixels = (double)rec.n * cfg.min_corner_rate;
+                if (minDistSq < minCornerDistancePixels * minCornerDistancePixels) ok = false;
+                for (int j = 0; j < 4; j++)
+                    if (q[j].x < cfg.min_border_dist || q[j].y < cfg.min_border_dist ||
+                        q[j].x > cfg.cols - 1 - cfg.min_border_dist || q[j].y > cfg.rows - 1 - cfg.min_border_dist)
+                        ok = false;
+            }
+            if (ok && lane == 0) {
+                unsigned k = atomicAdd(&n_cand[f], 1u);
+                if (k < (unsigned)kCandMax) {
+                    CandRec c;
+                    for (int j = 0; j < 4; j++) { c.x[j] = (short)q[j].x; c.y[j] = (short)q[j].y; }
+                    c.n = rec.n;
+                    c.ordkey = rec.scale * (1u << 22) + ((1u << 22) - 1u - rec.key);
+                    cands[(size_t)f * kCandMax + k] = c;
+                } else {
+                    atomicOr(&ctr->overflow, (unsigned)kOvfCands);
                 }
             }
         }
@@ -418,7 +549,7 @@ __global__ __launch_bounds__(1024) void k_assemble(DetectCfg cfg, Counters* ctr,
     __shared__ unsigned sPairSorted[kPairMax];     // lexicographic (i, j) order
     __shared__ unsigned char removed[kCandMax];
     __shared__ int outPos[kCandMax];
-    __shared__ unsigned sNPair;
+    __shared__ unsigned sNPair, sWorkBase;
     const int tid = threadIdx.x;
     const int f = blockIdx.x;
     const int C = (int)min(n_cand[f], (unsigned)kCandMax);
@@ -498,6 +629,7 @@ __global__ __launch_bounds__(1024) void k_assemble(DetectCfg cfg, Counters* ctr,
         int k = 0;
         for (int i = 0; i < C; i++) { outPos[i] = removed[i] ? -1 : k; k += removed[i] ? 0 : 1; }
         n_final[f] = (unsigned)k;
+        sWorkBase = k > 0 ? atomicAdd(&ctr->n_ident, (unsigned)k) : 0u;
     }
     __syncthreads();
     for (int i = tid; i < C; i += AT) {
@@ -509,8 +641,7 @@ __global__ __launch_bounds__(1024) void k_assemble(DetectCfg cfg, Counters* ctr,
             fc.id = -1;
             fc.pad[0] = fc.pad[1] = 0;
             finals[(size_t)f * kCandMax + k] = fc;
-            unsigned wi = atomicAdd(&ctr->n_ident, 1u);
-            work[wi] = IdentWork{(unsigned)f, (unsigned)k};
+            work[sWorkBase + k] = IdentWork{(unsigned)f, (unsigned)k};
         }
     }
 }
@@ -725,17 +856,22 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
 // host launchers
 // ------------------------------------------------------------------------------------------------
 void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t frame_stride, size_t row_step, int nframes,
-                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned long long* starts, Counters* ctr) {
+                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, Counters* ctr) {
     dim3 grid((cfg.cols + TW - 1) / TW, (cfg.rows + TH - 1) / TH, nframes);
-    hipLaunchKernelGGL(k_threshold, grid, dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg, starts, ctr);
+    hipLaunchKernelGGL(k_threshold, grid, dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg, starts, n_starts, ctr);
 }
-void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, const unsigned long long* starts,
-                  Counters* ctr, ContourRec* contours, unsigned* points) {
-    hipLaunchKernelGGL(k_trace, dim3(nwaves), dim3(64), 0, st, nbr, cfg, starts, ctr, contours, points);
+void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre) {
+    hipLaunchKernelGGL(k_prefix, dim3(1), dim3(256), 0, st, nframes, counts, cap, per_ticket, pre);
 }
-void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, Counters* ctr, const ContourRec* contours,
-                  const unsigned* points, CandRec* cands, unsigned* n_cand) {
-    hipLaunchKernelGGL(k_quads, dim3(nwaves), dim3(64), 0, st, cfg, ctr, contours, points, cands, n_cand);
+void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
+                  const unsigned* n_starts, const unsigned* pre, Counters* ctr, ContourRec* contours, unsigned* n_contours,
+                  unsigned* points, unsigned* n_points) {
+    hipLaunchKernelGGL(k_trace, dim3(nwaves), dim3(64), 0, st, nbr, cfg, nframes, starts, n_starts, pre, ctr, contours, n_contours,
+                       points, n_points);
+}
+void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, int nframes, Counters* ctr, const ContourRec* contours,
+                  const unsigned* n_contours, const unsigned* pre, const unsigned* points, CandRec* cands, unsigned* n_cand) {
+    hipLaunchKernelGGL(k_quads, dim3(nwaves), dim3(64), 0, st, cfg, nframes, ctr, contours, n_contours, pre, points, cands, n_cand);
 }
 void launch_assemble(hipStream_t st, int nframes, const DetectCfg& cfg, Counters* ctr, const CandRec* cands,
                      const unsigned* n_cand, FinalCand* finals, unsigned* n_final, IdentWork* work) {
@@ -745,5 +881,6 @@ void launch_identify(hipStream_t st, int nwaves, const DetectCfg& cfg, Counters*
                      FinalCand* finals, const IdentWork* work, const unsigned long long* dict_codes) {
     hipLaunchKernelGGL(k_identify, dim3(nwaves), dim3(64), 0, st, cfg, ctr, gray, finals, work, dict_codes);
 }
+int max_frames_per_call() { return kMaxFramesPerCall; }
 
 } // namespace aslam

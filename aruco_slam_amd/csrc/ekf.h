@@ -36,6 +36,7 @@ struct EkfState {
     int* d_id2idx;
     int* d_idx2id;
     LastObs* d_last;
+    LastObs* d_lastNext;               // staging of the next frame's list while the current one is still read
     int* d_nlast;
     PopRec* d_pop;
     int* d_npop;

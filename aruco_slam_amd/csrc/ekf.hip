@@ -109,30 +109,39 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
                                                   const ObsRaw* __restrict__ obs, const unsigned* __restrict__ n_markers,
                                                   Counters* ctr) {
     __shared__ double sH[9], sQ[9];
+    __shared__ ObsRaw sObs[kMarkerMax];
     __shared__ int sHeap[kMarkerMax];          // heap of observation slots
-    __shared__ int sIndex[kMarkerMax];         // aruco_index_ per slot
+    __shared__ int sIndex[kMarkerMax];         // aruco_index_ per slot (-1 new, -2 dropped by the gates)
     __shared__ int sOrder[kMarkerMax];         // pop order
-    __shared__ int sNPop, sL, sM;
+    __shared__ int sAction[kMarkerMax];        // per popped observation
+    __shared__ int sUpdPos[kMarkerMax];        // position in the fused update list (-1 = none)
+    __shared__ int sNPop, sL, sM, sNNew;
     __shared__ double sG[9], sMM[9], sNew[3];
     __shared__ int sDoAug;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int ld = E.ld;
 
-    int L = *E.d_L;
-    if (do_predict) predict_block(E, sp, wl, wr, dt, 3 + 3 * L, sH, sQ);
+    const int L0 = *E.d_L;
+    if (do_predict) predict_block(E, sp, wl, wr, dt, 3 + 3 * L0, sH, sQ);
 
     const int nM = (int)min(*n_markers, (unsigned)kMarkerMax);
     const double mu0x = E.d_mu[0], mu0y = E.d_mu[1], mu0t = E.d_mu[2];     // frozen pre-frame robot pose (Q1)
 
+    for (int i = tid; i < nM; i += nt) {
+        ObsRaw o = obs[i];
+        sObs[i] = o;
+        int index = -2;
+        if (o.valid) index = (o.id >= 0 && o.id < kIdTableSize) ? E.d_id2idx[o.id] : -1;   // checkLandmark (aruco_slam.cpp:423-435)
+        sIndex[i] = index;
+    }
+    __syncthreads();
     if (tid == 0) {
         // obs_.push(ob) in detection order (aruco_slam.cpp:369-373): libstdc++ std::priority_queue = push_heap
         // with operator< inverted on aruco_index_ (aruco_slam.h:85-88): new markers (-1) first, then ascending index
-        int len = 0;
+        int len = 0, nnew = 0;
         for (int i = 0; i < nM; i++) {
-            if (!obs[i].valid) continue;
-            int id = obs[i].id;
-            int index = (id >= 0 && id < kIdTableSize) ? E.d_id2idx[id] : -1;      // checkLandmark (aruco_slam.cpp:423-435)
-            sIndex[i] = index;
+            if (sIndex[i] == -2) continue;
+            nnew += sIndex[i] < 0;
             int hole = len++, value = i;
             int parent = (hole - 1) / 2;
             while (hole > 0 && sIndex[sHeap[parent]] > sIndex[value]) {            // comp(parent, value) = parent < value
@@ -171,136 +180,141 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
             len--;
         }
         sNPop = np;
-        sL = L;
+        sNNew = nnew;
+        sL = L0;
         sM = 0;
     }
     __syncthreads();
     const int np = sNPop;
+    const int nnew = sNNew;
 
-    for (int q = 0; q < np; q++) {
+    // ---- new landmarks first (they pop first): strictly sequential (aruco_slam.cpp:208-260) ----
+    for (int q = 0; q < nnew; q++) {
         const int slot = sOrder[q];
-        const int index = sIndex[slot];
-        if (index < 0) {
-            // ---- new landmark (aruco_slam.cpp:208-260) ----
-            if (tid == 0) {
-                const ObsRaw o = obs[slot];
-                L = sL;
-                PopRec pr;
-                pr.id = o.id; pr.index = -1; pr.action = 0; pr.pad = 0;
-                pr.z[0] = o.x; pr.z[1] = o.y; pr.z[2] = o.th;
-                pr.r[0] = o.r[0]; pr.r[1] = o.r[1]; pr.r[2] = o.r[2];
-                E.d_pop[q] = pr;
-                if (L >= E.max_landmarks) {
-                    atomicOr(&ctr->overflow, (unsigned)kOvfLandmarks);
-                    sDoAug = 0;
-                } else {
-                    sDoAug = 1;
-                    float sinth = (float)sin(mu0t);                               // float trig (quirk Q4)
-                    float costh = (float)cos(mu0t);
-                    double map_x = mu0x + costh * o.x - sinth * o.y;
-                    double map_y = mu0y + sinth * o.x + costh * o.y;
-                    double map_theta = mu0t + o.th;
-                    wrap1(map_theta);
-                    sNew[0] = map_x; sNew[1] = map_y; sNew[2] = map_theta;
-                    double deltax = map_x - mu0x, deltay = map_y - mu0y;
-                    double Gsk[9] = {-costh, -sinth, -sinth * deltax + costh * deltay,
-                                     sinth, -costh, -deltax * costh - deltay * sinth,
-                                     0, 0, -1};
-                    double Gmi[9] = {costh, sinth, 0, -sinth, costh, 0, 0, 0, 1};
-                    double ss[9], T1[9], T2[9], T3[9];
-                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ss[i * 3 + j] = E.d_sigma[(size_t)j * ld + i];
-                    // sigma_mm = Gmi * (Gsk*sigma_s*Gsk^T + Rk)^T * Gmi^T   (quirk Q5, literal)
-                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-                        double s = 0; for (int k = 0; k < 3; k++) s += Gsk[i * 3 + k] * ss[k * 3 + j]; T1[i * 3 + j] = s; }
-                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-                        double s = 0; for (int k = 0; k < 3; k++) s += T1[i * 3 + k] * Gsk[j * 3 + k];
-                        T2[i * 3 + j] = s + (i == j ? o.r[i] : 0.0); }
-                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-                        double s = 0; for (int k = 0; k < 3; k++) s += Gmi[i * 3 + k] * T2[j * 3 + k]; T3[i * 3 + j] = s; }
-                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-                        double s = 0; for (int k = 0; k < 3; k++) s += T3[i * 3 + k] * Gmi[j * 3 + k]; sMM[i * 3 + j] = s; }
-                    // sigma_mx = (-Gmi * Gsk) * sigma_.topRows(3)
-                    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
-                        double s = 0; for (int k = 0; k < 3; k++) s += (-Gmi[i * 3 + k]) * Gsk[k * 3 + j]; sG[i * 3 + j] = s; }
-                }
+        if (tid == 0) {
+            const ObsRaw o = sObs[slot];
+            sAction[q] = 0;
+            if (sL >= E.max_landmarks) {
+                atomicOr(&ctr->overflow, (unsigned)kOvfLandmarks);
+                sDoAug = 0;
+            } else {
+                sDoAug = 1;
+                float sinth = (float)sin(mu0t);                               // float trig (quirk Q4)
+                float costh = (float)cos(mu0t);
+                double map_x = mu0x + costh * o.x - sinth * o.y;
+                double map_y = mu0y + sinth * o.x + costh * o.y;
+                double map_theta = mu0t + o.th;
+                wrap1(map_theta);
+                sNew[0] = map_x; sNew[1] = map_y; sNew[2] = map_theta;
+                double deltax = map_x - mu0x, deltay = map_y - mu0y;
+                double Gsk[9] = {-costh, -sinth, -sinth * deltax + costh * deltay,
+                                 sinth, -costh, -deltax * costh - deltay * sinth,
+                                 0, 0, -1};
+                double Gmi[9] = {costh, sinth, 0, -sinth, costh, 0, 0, 0, 1};
+                double ss[9], T1[9], T2[9], T3[9];
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ss[i * 3 + j] = E.d_sigma[(size_t)j * ld + i];
+                // sigma_mm = Gmi * (Gsk*sigma_s*Gsk^T + Rk)^T * Gmi^T   (quirk Q5, literal)
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                    double s = 0; for (int k = 0; k < 3; k++) s += Gsk[i * 3 + k] * ss[k * 3 + j]; T1[i * 3 + j] = s; }
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                    double s = 0; for (int k = 0; k < 3; k++) s += T1[i * 3 + k] * Gsk[j * 3 + k];
+                    T2[i * 3 + j] = s + (i == j ? o.r[i] : 0.0); }
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                    double s = 0; for (int k = 0; k < 3; k++) s += Gmi[i * 3 + k] * T2[j * 3 + k]; T3[i * 3 + j] = s; }
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                    double s = 0; for (int k = 0; k < 3; k++) s += T3[i * 3 + k] * Gmi[j * 3 + k]; sMM[i * 3 + j] = s; }
+                // sigma_mx = (-Gmi * Gsk) * sigma_.topRows(3)
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                    double s = 0; for (int k = 0; k < 3; k++) s += (-Gmi[i * 3 + k]) * Gsk[k * 3 + j]; sG[i * 3 + j] = s; }
             }
-            __syncthreads();
-            if (sDoAug) {
-                const int N = 3 + 3 * sL;
-                for (int c = tid; c < N; c += nt) {
-                    const double* col = E.d_sigma + (size_t)c * ld;
-                    double a = col[0], b = col[1], d = col[2];
-                    for (int i = 0; i < 3; i++) {
-                        double v = sG[i * 3] * a + sG[i * 3 + 1] * b + sG[i * 3 + 2] * d;
-                        E.d_sigma[(size_t)c * ld + N + i] = v;            // bottom-left block: sigma_mx
-                        E.d_sigma[(size_t)(N + i) * ld + c] = v;          // top-right block: sigma_mx^T
-                    }
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    for (int i = 0; i < 3; i++)
-                        for (int j = 0; j < 3; j++) E.d_sigma[(size_t)(N + j) * ld + N + i] = sMM[i * 3 + j];
-                    E.d_mu[N] = sNew[0]; E.d_mu[N + 1] = sNew[1]; E.d_mu[N + 2] = sNew[2];
-                    const int id = obs[slot].id;
-                    if (id >= 0 && id < kIdTableSize && E.d_id2idx[id] < 0) E.d_id2idx[id] = sL;   // map::insert keeps the first (Q10)
-                    E.d_idx2id[sL] = id;
-                    sL = sL + 1;
-                }
-            }
-            __syncthreads();
-        } else {
-            // ---- already mapped (aruco_slam.cpp:108-207) ----
-            if (tid == 0) {
-                const ObsRaw o = obs[slot];
-                const int li = 3 + 3 * index;
-                double z[3] = {o.x, o.y, o.th};
-                // "stationary" test against the previous frame (aruco_slam.cpp:192-198): a no-op branch (quirk Q2)
-                bool stationary = false;
-                const int nl = *E.d_nlast;
-                for (int k = 0; k < nl; k++)
-                    if (E.d_last[k].id == o.id) {                                  // std::find: first with the same id
-                        double d0 = E.d_last[k].z[0] - z[0], d1 = E.d_last[k].z[1] - z[1], d2 = E.d_last[k].z[2] - z[2];
-                        stationary = sqrt(d0 * d0 + d1 * d1 + d2 * d2) < 0.01;     // NaN compares false (Q2/Q3)
-                        break;
-                    }
-                PopRec pr;
-                pr.id = o.id; pr.index = index; pr.action = stationary ? 2 : 1; pr.pad = 0;
-                pr.z[0] = z[0]; pr.z[1] = z[1]; pr.z[2] = z[2];
-                pr.r[0] = o.r[0]; pr.r[1] = o.r[1]; pr.r[2] = o.r[2];
-                E.d_pop[q] = pr;
-                if (!stationary) {
-                    double mx = E.d_mu[li], my = E.d_mu[li + 1], mth = E.d_mu[li + 2];   // unchanged since frame start
-                    double sintheta = sin(mu0t), costheta = cos(mu0t);
-                    double gdx = mx - mu0x, gdy = my - mu0y, gdth = mth - mu0t;
-                    wrap1(gdth);
-                    double zh0 = gdx * costheta + gdy * sintheta, zh1 = -gdx * sintheta + gdy * costheta;
-                    UpdRec u;
-                    u.li = li; u.pad = 0;
-                    u.ze[0] = z[0] - zh0; u.ze[1] = z[1] - zh1; u.ze[2] = z[2] - gdth;
-                    wrap1(u.ze[2]);
-                    const double G[18] = {-costheta, -sintheta, -gdx * sintheta + gdy * costheta, costheta, sintheta, 0,
-                                          sintheta, -costheta, -gdx * costheta - gdy * sintheta, -sintheta, costheta, 0,
-                                          0, 0, -1, 0, 0, 1};
-                    for (int k = 0; k < 18; k++) u.Gxm[k] = G[k];
-                    u.r[0] = o.r[0]; u.r[1] = o.r[1]; u.r[2] = o.r[2];
-                    E.d_upd[sM] = u;
-                    sM = sM + 1;
-                }
-            }
-            __syncthreads();
         }
+        __syncthreads();
+        if (sDoAug) {
+            const int N = 3 + 3 * sL;
+            for (int c = tid; c < N; c += nt) {
+                const double* col = E.d_sigma + (size_t)c * ld;
+                double a = col[0], b = col[1], d = col[2];
+                for (int i = 0; i < 3; i++) {
+                    double v = sG[i * 3] * a + sG[i * 3 + 1] * b + sG[i * 3 + 2] * d;
+                    E.d_sigma[(size_t)c * ld + N + i] = v;            // bottom-left block: sigma_mx
+                    E.d_sigma[(size_t)(N + i) * ld + c] = v;          // top-right block: sigma_mx^T
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) E.d_sigma[(size_t)(N + j) * ld + N + i] = sMM[i * 3 + j];
+                E.d_mu[N] = sNew[0]; E.d_mu[N + 1] = sNew[1]; E.d_mu[N + 2] = sNew[2];
+                const int id = sObs[slot].id;
+                if (id >= 0 && id < kIdTableSize && E.d_id2idx[id] < 0) E.d_id2idx[id] = sL;   // map::insert keeps the first (Q10)
+                E.d_idx2id[sL] = id;
+                sL = sL + 1;
+            }
+        }
+        __syncthreads();
     }
+
+    // ---- already mapped (aruco_slam.cpp:108-207): every record is independent of the others (frozen mean, Q1) ----
+    const int nl = *E.d_nlast;
+    for (int q = nnew + tid; q < np; q += nt) {
+        const ObsRaw o = sObs[sOrder[q]];
+        // "stationary" test against the previous frame (aruco_slam.cpp:192-198): a no-op branch (quirk Q2)
+        bool stationary = false;
+        for (int k = 0; k < nl; k++)
+            if (E.d_last[k].id == o.id) {                                  // std::find: first with the same id
+                double d0 = E.d_last[k].z[0] - o.x, d1 = E.d_last[k].z[1] - o.y, d2 = E.d_last[k].z[2] - o.th;
+                stationary = sqrt(d0 * d0 + d1 * d1 + d2 * d2) < 0.01;     // NaN compares false (Q2/Q3)
+                break;
+            }
+        sAction[q] = stationary ? 2 : 1;
+    }
+    __syncthreads();
     if (tid == 0) {
+        int m = 0;
+        for (int q = 0; q < np; q++) sUpdPos[q] = (q >= nnew && sAction[q] == 1) ? m++ : -1;
+        sM = m;
+    }
+    __syncthreads();
+    for (int q = tid; q < np; q += nt) {
+        const int slot = sOrder[q];
+        const ObsRaw o = sObs[slot];
+        const int index = sIndex[slot];
+        PopRec pr;
+        pr.id = o.id; pr.index = index; pr.action = sAction[q]; pr.pad = 0;
+        pr.z[0] = o.x; pr.z[1] = o.y; pr.z[2] = o.th;
+        pr.r[0] = o.r[0]; pr.r[1] = o.r[1]; pr.r[2] = o.r[2];
+        E.d_pop[q] = pr;
         // last_observed_marker_ = observed_marker (aruco_slam.cpp:263): last_observation_ is only ever set in the
         // update branch (:202); everywhere else it stays unset -> NaN sentinel
-        const double qnan = nan("");
-        for (int q = 0; q < np; q++) {
-            LastObs lo;
-            lo.id = E.d_pop[q].id; lo.pad = 0;
-            if (E.d_pop[q].action == 1) { lo.z[0] = E.d_pop[q].z[0]; lo.z[1] = E.d_pop[q].z[1]; lo.z[2] = E.d_pop[q].z[2]; }
-            else { lo.z[0] = lo.z[1] = lo.z[2] = qnan; }
-            E.d_last[q] = lo;
+        LastObs lo;
+        lo.id = o.id; lo.pad = 0;
+        if (sAction[q] == 1) { lo.z[0] = o.x; lo.z[1] = o.y; lo.z[2] = o.th; }
+        else { lo.z[0] = lo.z[1] = lo.z[2] = nan(""); }
+        E.d_lastNext[q] = lo;
+        const int up = sUpdPos[q];
+        if (up >= 0) {
+            const int li = 3 + 3 * index;
+            double mx = E.d_mu[li], my = E.d_mu[li + 1], mth = E.d_mu[li + 2];   // unchanged since frame start
+            double sintheta = sin(mu0t), costheta = cos(mu0t);
+            double gdx = mx - mu0x, gdy = my - mu0y, gdth = mth - mu0t;
+            wrap1(gdth);
+            double zh0 = gdx * costheta + gdy * sintheta, zh1 = -gdx * sintheta + gdy * costheta;
+            UpdRec u;
+            u.li = li; u.pad = 0;
+            u.ze[0] = o.x - zh0; u.ze[1] = o.y - zh1; u.ze[2] = o.th - gdth;
+            wrap1(u.ze[2]);
+            const double G[18] = {-costheta, -sintheta, -gdx * sintheta + gdy * costheta, costheta, sintheta, 0,
+                                  sintheta, -costheta, -gdx * costheta - gdy * sintheta, -sintheta, costheta, 0,
+                                  0, 0, -1, 0, 0, 1};
+            for (int k = 0; k < 18; k++) u.Gxm[k] = G[k];
+            u.r[0] = o.r[0]; u.r[1] = o.r[1]; u.r[2] = o.r[2];
+            E.d_upd[up] = u;
         }
+    }
+    __syncthreads();
+    // the previous frame's list was read above by every thread; publish the new one for the next frame
+    for (int q = tid; q < np; q += nt) E.d_last[q] = E.d_lastNext[q];
+    if (tid == 0) {
         *E.d_nlast = np;
         *E.d_npop = np;
         *E.d_L = sL;
@@ -308,21 +322,23 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     }
 }
 
-// ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns) -----------------------------------------------
+// ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns); grid (columns / 256, update slices) -----------
 __global__ __launch_bounds__(256) void k_ekf_gather(EkfState E) {
     const int m = *E.d_m;
     const int N = 3 + 3 * (*E.d_L);
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int ld = E.ld;
-    if (m > 0 && t < N) {
+    if (t < N) {
         const double* col = E.d_sigma + (size_t)t * ld;           // column t: Sigma(:, t)
         const double c0 = col[0], c1 = col[1], c2 = col[2];
         const double r0 = E.d_sigma[t], r1 = E.d_sigma[(size_t)ld + t], r2 = E.d_sigma[(size_t)2 * ld + t];   // Sigma(t, 0..2)
-        for (int k = 0; k < m; k++) {
+        for (int k = blockIdx.y; k < m; k += gridDim.y) {
             const UpdRec& u = E.d_upd[k];
-            const double l0 = col[u.li], l1 = col[u.li + 1], l2 = col[u.li + 2];
-            const double q0 = E.d_sigma[(size_t)u.li * ld + t], q1 = E.d_sigma[(size_t)(u.li + 1) * ld + t],
-                         q2 = E.d_sigma[(size_t)(u.li + 2) * ld + t];
+            const int li = u.li;
+            const double l0 = col[li], l1 = col[li + 1], l2 = col[li + 2];
+            const double q0 = E.d_sigma[(size_t)li * ld + t], q1 = E.d_sigma[(size_t)(li + 1) * ld + t],
+                         q2 = E.d_sigma[(size_t)(li + 2) * ld + t];
+#pragma unroll
             for (int a = 0; a < 3; a++) {
                 const double* g = &u.Gxm[a * 6];
                 E.d_V[(size_t)(3 * k + a) * ld + t] = g[0] * c0 + g[1] * c1 + g[2] * c2 + g[3] * l0 + g[4] * l1 + g[5] * l2;
@@ -339,10 +355,11 @@ __global__ __launch_bounds__(256) void k_ekf_gather(EkfState E) {
 //   alpha_i. = e_i - sum_{j<i} D_ij alpha_j.             beta_.i = e_i - sum_{j<i} gamma_.j C_ji
 //   gamma_.i = beta_.i S_i^-1                            G = sum_i gamma_.i alpha_i.      g = sum_i gamma_.i ze_i
 // where Sv_li = V_l H_i^T and Sw_il = H_i W_l are the 3x3 blocks of H Sigma0 H^T taken from rows / columns.
-__global__ __launch_bounds__(256) void k_ekf_small(EkfState E) {
-    __shared__ double sC[kMarkerMax * 9], sD[kMarkerMax * 9];
-    __shared__ double sBeta[3 * kMarkerMax * 3];
-    __shared__ double sSinv[9];
+__device__ void ekf_small_general(const EkfState& E, double* scratch /* >= 2*9*kMarkerMax + 9*kMarkerMax + 9 doubles of LDS */) {
+    double* sC = scratch;
+    double* sD = scratch + kMarkerMax * 9;
+    double* sBeta = scratch + 2 * kMarkerMax * 9;
+    double* sSinv = scratch + 3 * kMarkerMax * 9;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int m = *E.d_m;
     const int n3 = 3 * m;
@@ -430,6 +447,88 @@ __global__ __launch_bounds__(256) void k_ekf_small(EkfState E) {
         double s = 0;
         for (int q = r / 3 * 3; q < n3; q++) s += ga[(size_t)r * n3 + q] * E.d_upd[q / 3].ze[q % 3];
         E.d_g[r] = s;
+    }
+}
+
+// ---- small (fast path, 3m <= kSmallMax): the innovation matrix in LDS --------------------------------------
+// In exact arithmetic the M sequential rank-3 corrections equal ONE batch correction with A = H Sigma0 H^T + blockdiag(R):
+// G = A^-1 (the matrix-inversion lemma needs no symmetry).  The reference, however, feeds every update the innovation
+// computed at the frozen pre-frame mean (quirk Q1) instead of the running one, i.e. the batch filter sees the pseudo
+// innovations nu_i = ze_i + sum_{j<i} (H_i K_j) ze_j = (L_blk ze)_i, with L_blk the block-unit-lower factor of A.
+// With the scalar LU A = L' U'' (no pivoting; A is an SPD innovation covariance), L_blk = L' diag(L'_ii)^-1, so
+//     nu = L' ze_hat ,  ze_hat_i = L'_ii^-1 ze_i ,  g = A^-1 nu ,  G = A^-1 .
+// A^-1 is formed by in-place Gauss-Jordan in LDS; the multipliers of the rows below each pivot are exactly L'.
+constexpr int kSmallMax = 96;            // 3m <= 96 (m <= 32 fused updates) runs out of LDS; larger frames use the general path
+
+__global__ __launch_bounds__(512) void k_ekf_small(EkfState E) {
+    __shared__ double sA[kSmallMax * kSmallMax];
+    __shared__ double sLm[kSmallMax * kSmallMax];
+    __shared__ double sCol[kSmallMax], sRow[kSmallMax];
+    __shared__ double sZe[kSmallMax], sNu[kSmallMax];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int m = *E.d_m;
+    const int n3 = 3 * m;
+    const int ld = E.ld;
+    if (n3 > kSmallMax) {                      // uniform branch
+        ekf_small_general(E, sA);
+    } else if (m > 0) {
+        // A[(3i+a)][(3j+b)] = (V_i H_j^T)[a][b] + delta_ij R_i[a][b]   (aruco_slam.cpp:146: (Gx*sigma_)*Gx^T + Rk)
+        for (int p = tid; p < n3 * n3; p += nt) {
+            const int rr = p / n3, cc = p - rr * n3;
+            const int j = cc / 3, b = cc - 3 * j;
+            const UpdRec& u = E.d_upd[j];
+            const double* v = E.d_V + (size_t)rr * ld;
+            const double* g = &u.Gxm[b * 6];
+            double a = v[0] * g[0] + v[1] * g[1] + v[2] * g[2] + v[u.li] * g[3] + v[u.li + 1] * g[4] + v[u.li + 2] * g[5];
+            if (rr == cc) a += u.r[b];
+            sA[p] = a;
+            sLm[p] = (rr == cc) ? 1.0 : 0.0;
+        }
+        for (int r = tid; r < n3; r += nt) sZe[r] = E.d_upd[r / 3].ze[r % 3];
+        __syncthreads();
+        for (int k = 0; k < n3; k++) {
+            // snapshot pivot column and pivot row
+            for (int i = tid; i < 2 * n3; i += nt) {
+                if (i < n3) sCol[i] = sA[i * n3 + k];
+                else sRow[i - n3] = sA[k * n3 + (i - n3)];
+            }
+            __syncthreads();
+            const double ip = 1.0 / sCol[k];
+            for (int p = tid; p < n3 * n3; p += nt) {
+                const int r = p / n3, c = p - r * n3;
+                const double rk = (c == k) ? 1.0 : sRow[c];        // pivot row with its pivot column replaced by e_k
+                if (r == k) {
+                    sA[p] = rk * ip;
+                } else {
+                    const double f = sCol[r];
+                    const double cur = (c == k) ? 0.0 : sA[p];
+                    sA[p] = cur - f * (rk * ip);
+                    if (c == k && r > k) sLm[p] = f * ip;          // LU multiplier L'[r][k]
+                }
+            }
+            __syncthreads();
+        }
+        // ze_hat_i = L'_ii^-1 ze_i (3x3 unit lower), nu = L' ze_hat
+        if (tid < m) {
+            const int i = tid, o = 3 * i;
+            double z0 = sZe[o];
+            double z1 = sZe[o + 1] - sLm[(o + 1) * n3 + o] * z0;
+            double z2 = sZe[o + 2] - sLm[(o + 2) * n3 + o] * z0 - sLm[(o + 2) * n3 + o + 1] * z1;
+            sZe[o] = z0; sZe[o + 1] = z1; sZe[o + 2] = z2;
+        }
+        __syncthreads();
+        for (int r = tid; r < n3; r += nt) {
+            double s = 0;
+            for (int c = 0; c <= r; c++) s += sLm[r * n3 + c] * sZe[c];
+            sNu[r] = s;
+        }
+        __syncthreads();
+        for (int p = tid; p < n3 * n3; p += nt) E.d_G[p] = sA[p];
+        for (int r = tid; r < n3; r += nt) {
+            double s = 0;
+            for (int c = 0; c < n3; c++) s += sA[r * n3 + c] * sNu[c];
+            E.d_g[r] = s;
+        }
     }
 }
 
@@ -535,6 +634,7 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks) {
     A(dalloc(&E.d_id2idx, kIdTableSize));
     A(dalloc(&E.d_idx2id, (size_t)max_landmarks));
     A(dalloc(&E.d_last, kMarkerMax));
+    A(dalloc(&E.d_lastNext, kMarkerMax));
     A(dalloc(&E.d_nlast, 1));
     A(dalloc(&E.d_pop, kMarkerMax));
     A(dalloc(&E.d_npop, 1));
@@ -564,7 +664,7 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks) {
 }
 
 void ekf_free(EkfState& E) {
-    hipFree(E.d_mu); hipFree(E.d_sigma); hipFree(E.d_L); hipFree(E.d_id2idx); hipFree(E.d_idx2id); hipFree(E.d_last);
+    hipFree(E.d_mu); hipFree(E.d_sigma); hipFree(E.d_L); hipFree(E.d_id2idx); hipFree(E.d_idx2id); hipFree(E.d_last); hipFree(E.d_lastNext);
     hipFree(E.d_nlast); hipFree(E.d_pop); hipFree(E.d_npop); hipFree(E.d_upd); hipFree(E.d_m); hipFree(E.d_V); hipFree(E.d_Wt);
     hipFree(E.d_T); hipFree(E.d_Sv); hipFree(E.d_Sw); hipFree(E.d_alpha); hipFree(E.d_gamma); hipFree(E.d_G); hipFree(E.d_g);
     hipFree(E.d_maprec);
@@ -579,10 +679,10 @@ void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, do
     hipLaunchKernelGGL(k_ekf_plan, dim3(1), dim3(256), 0, st, E, sp, wl, wr, dt, do_predict, obs, n_markers, ctr);
 }
 void launch_ekf_gather(hipStream_t st, const EkfState& E) {
-    hipLaunchKernelGGL(k_ekf_gather, dim3((E.ld + 255) / 256), dim3(256), 0, st, E);
+    hipLaunchKernelGGL(k_ekf_gather, dim3((E.ld + 255) / 256, 32), dim3(256), 0, st, E);
 }
 void launch_ekf_small(hipStream_t st, const EkfState& E) {
-    hipLaunchKernelGGL(k_ekf_small, dim3(1), dim3(256), 0, st, E);
+    hipLaunchKernelGGL(k_ekf_small, dim3(1), dim3(512), 0, st, E);
 }
 void launch_ekf_T(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_T, dim3((E.ld + 63) / 64, 16), dim3(256), 0, st, E);

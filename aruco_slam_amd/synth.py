@@ -111,8 +111,8 @@ CONFIGS = {
     # BASELINE.json configs[0..2]; cfg1 uses 3 panels of 4 (12 landmarks) — see DESIGN.md
     "cfg1": SceneConfig(rows=480, cols=640, f=450.0, grid=(2, 2), n_panels=3, col_spacing=0.9, row_spacing=0.7),
     "cfg2": SceneConfig(),
-    "cfg3": SceneConfig(rows=1080, cols=1920, f=1200.0, grid=(10, 5), n_panels=20, col_spacing=0.40, row_spacing=0.34,
-                        tz_far=2.60, tz_near=2.05),
+    "cfg3": SceneConfig(rows=1080, cols=1920, f=1000.0, grid=(10, 5), n_panels=20, col_spacing=0.36, row_spacing=0.34,
+                        tz_far=2.3, tz_near=2.0, max_yaw_deg=20.0),
 }
 
 
@@ -162,9 +162,7 @@ class PanelWorld:
         fpp = self.frames_per_panel
         lap_pos = index % self.lap_length()
         k, j = divmod(lap_pos, fpp)
-        # after a whole lap the polygon closes only in heading; the position is re-based to the lap's start so that
-        # every lap sees identical geometry (the robot "teleports" by the polygon's closing gap, which the reference
-        # arithmetic neither knows nor cares about: it only sees encoders and images)
+        # the tour is a closed regular polygon (equal sides, equal turns), so every lap sees identical geometry
         phi = self.heading[k]
         u = np.array([math.cos(phi), math.sin(phi)])
         p = self.vertex[k] + j * cfg.step * u

@@ -6,9 +6,10 @@
 // GPU-less container before the same sources are run on a real MI355X through gpurun.  It is NOT
 // a fallback: the shipped library is always the hipcc/gfx950 build and fails loudly without a GPU.
 //
-// Model: blocks run one after another; the threads of a block are real OS threads joined by a
-// barrier (__syncthreads); a wave is 64 consecutive threads sharing a second barrier for
-// __shfl/__ballot (which must be called by every lane of the wave, as in the product code).
+// Model: every block runs in one OS thread (several blocks in parallel on the host cores); its threads are
+// cooperative coroutines (ucontext) that switch at __syncthreads and at wave collectives (__shfl/__ballot,
+// which must be called by every live lane of the wave, as in the product code).  __shared__ variables are
+// thread_local statics, i.e. private to the block currently running on that OS thread.
 #pragma once
 #include <cstdint>
 #include <cstdlib>
@@ -19,12 +20,14 @@
 #include <vector>
 #include <chrono>
 #include <algorithm>
-#include <pthread.h>
+#include <ucontext.h>
+#include <atomic>
+#include <mutex>
 
 #define __global__
 #define __device__
 #define __host__
-#define __shared__ static
+#define __shared__ static thread_local
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
@@ -36,20 +39,38 @@ struct dim3 {
 struct uint3_emu { unsigned x, y, z; };
 
 namespace hipemu {
+struct Lane {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+    uint3_emu tidx;
+    int lane, wave;
+};
 struct WaveCtx {
-    pthread_barrier_t bar;
     unsigned long long slot[64];
-    int lanes;
+    int lanes = 0;        // lanes that exist
+    int live = 0;         // lanes that have not returned yet
+    int arrived = 0;
+    unsigned gen = 0;
 };
 struct BlockCtx {
-    pthread_barrier_t bar;
+    std::vector<Lane> lanes;
     std::vector<WaveCtx> waves;
+    ucontext_t sched;
+    int cur = 0;
+    int live = 0;         // threads that have not returned
+    int arrived = 0;
+    unsigned gen = 0;
+    uint3_emu bidx;
 };
 inline thread_local uint3_emu t_threadIdx, t_blockIdx;
 inline thread_local int t_lane, t_wave;
 inline thread_local BlockCtx* t_block;
 inline dim3 g_blockDim, g_gridDim;
-alignas(16) inline unsigned char g_dynshared[160 * 1024];
+inline void yield_lane() {                     // back to the block scheduler, which resumes the next live lane
+    BlockCtx* b = t_block;
+    swapcontext(&b->lanes[b->cur].ctx, &b->sched);
+}
 }
 
 #define threadIdx (hipemu::t_threadIdx)
@@ -62,7 +83,12 @@ using std::max;
 using std::isfinite;
 using std::isnan;
 
-inline void __syncthreads() { pthread_barrier_wait(&hipemu::t_block->bar); }
+inline void __syncthreads() {
+    hipemu::BlockCtx* b = hipemu::t_block;
+    const unsigned g = b->gen;
+    if (++b->arrived >= b->live) { b->arrived = 0; b->gen++; return; }
+    while (b->gen == g) hipemu::yield_lane();
+}
 inline void __threadfence() { __sync_synchronize(); }
 inline void __threadfence_block() { __sync_synchronize(); }
 
@@ -70,12 +96,19 @@ namespace hipemu {
 template <class T> inline unsigned long long to_bits(T v) { unsigned long long b = 0; std::memcpy(&b, &v, sizeof(T)); return b; }
 template <class T> inline T from_bits(unsigned long long b) { T v; std::memcpy(&v, &b, sizeof(T)); return v; }
 inline WaveCtx& wave() { return t_block->waves[t_wave]; }
+inline void wave_sync() {                      // all live lanes of the wave
+    WaveCtx& w = wave();
+    const unsigned g = w.gen;
+    if (++w.arrived >= w.live) { w.arrived = 0; w.gen++; return; }
+    while (w.gen == g) yield_lane();
+}
 template <class T> inline T shfl_any(T v, int src) {
     WaveCtx& w = wave();
-    w.slot[t_lane] = to_bits(v);
-    pthread_barrier_wait(&w.bar);
+    const int me = t_lane;
+    w.slot[me] = to_bits(v);
+    wave_sync();
     T r = from_bits<T>(w.slot[src & 63]);
-    pthread_barrier_wait(&w.bar);
+    wave_sync();
     return r;
 }
 }
@@ -85,11 +118,12 @@ template <class T> inline T __shfl_up(T v, unsigned d, int = 64) { int s = hipem
 template <class T> inline T __shfl_xor(T v, int m, int = 64) { return hipemu::shfl_any(v, hipemu::t_lane ^ m); }
 inline unsigned long long __ballot(int pred) {
     hipemu::WaveCtx& w = hipemu::wave();
-    w.slot[hipemu::t_lane] = pred ? 1ull : 0ull;
-    pthread_barrier_wait(&w.bar);
+    const int me = hipemu::t_lane;
+    w.slot[me] = pred ? 1ull : 0ull;
+    hipemu::wave_sync();
     unsigned long long m = 0;
     for (int i = 0; i < w.lanes; i++) m |= (w.slot[i] & 1ull) << i;
-    pthread_barrier_wait(&w.bar);
+    hipemu::wave_sync();
     return m;
 }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
@@ -161,47 +195,80 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::g_dynshared);
 
 namespace hipemu {
-// kernels without barriers / wave ops listed here run their threads sequentially (fast path for per-pixel kernels)
-inline bool is_sequential(const char* name) {
-    static const char* seq[] = {"k_render", nullptr};
-    for (int i = 0; seq[i]; i++) if (std::strcmp(seq[i], name) == 0) return true;
-    return false;
-}
-template <class F> void run_grid(const char* name, dim3 grid, dim3 block, F&& body) {
-    g_blockDim = block;
-    g_gridDim = grid;
+constexpr size_t kStackBytes = 96 * 1024;
+template <class F> struct Tramp {
+    static void entry(unsigned lo, unsigned hi) {
+        F* f = reinterpret_cast<F*>(((unsigned long long)hi << 32) | lo);
+        (*f)();
+        BlockCtx* b = t_block;
+        Lane& me = b->lanes[b->cur];
+        me.done = true;
+        b->live--;
+        WaveCtx& w = b->waves[me.wave];
+        w.live--;
+        // a lane that returns may complete a pending barrier / collective of the others
+        if (b->live > 0 && b->arrived >= b->live) { b->arrived = 0; b->gen++; }
+        if (w.live > 0 && w.arrived >= w.live) { w.arrived = 0; w.gen++; }
+        swapcontext(&me.ctx, &b->sched);
+    }
+};
+template <class F> void run_block(F& body, dim3 block, unsigned bx, unsigned by, unsigned bz, std::vector<char>& stacks) {
     const int T = (int)(block.x * block.y * block.z);
     const int nw = (T + 63) / 64;
-    const bool seq = is_sequential(name);
-    for (unsigned bz = 0; bz < grid.z; bz++)
-        for (unsigned by = 0; by < grid.y; by++)
-            for (unsigned bx = 0; bx < grid.x; bx++) {
-                BlockCtx ctx;
-                pthread_barrier_init(&ctx.bar, nullptr, T);
-                ctx.waves.resize(nw);
-                for (int w = 0; w < nw; w++) {
-                    ctx.waves[w].lanes = std::min(64, T - 64 * w);
-                    pthread_barrier_init(&ctx.waves[w].bar, nullptr, ctx.waves[w].lanes);
-                }
-                auto worker = [&](int tid) {
-                    t_block = &ctx;
-                    t_blockIdx = uint3_emu{bx, by, bz};
-                    t_threadIdx = uint3_emu{(unsigned)(tid % block.x), (unsigned)((tid / block.x) % block.y), (unsigned)(tid / (block.x * block.y))};
-                    t_lane = tid & 63;
-                    t_wave = tid >> 6;
-                    body();
-                };
-                if (T == 1 || seq) {
-                    for (int t = 0; t < T; t++) worker(t);
-                } else {
-                    std::vector<std::thread> th;
-                    th.reserve(T);
-                    for (int t = 0; t < T; t++) th.emplace_back(worker, t);
-                    for (auto& x : th) x.join();
-                }
-                pthread_barrier_destroy(&ctx.bar);
-                for (int w = 0; w < nw; w++) pthread_barrier_destroy(&ctx.waves[w].bar);
-            }
+    BlockCtx ctx;
+    ctx.lanes.resize(T);
+    ctx.waves.resize(nw);
+    ctx.live = T;
+    ctx.bidx = uint3_emu{bx, by, bz};
+    if (stacks.size() < (size_t)T * kStackBytes) stacks.resize((size_t)T * kStackBytes);
+    for (int w = 0; w < nw; w++) { ctx.waves[w].lanes = std::min(64, T - 64 * w); ctx.waves[w].live = ctx.waves[w].lanes; }
+    t_block = &ctx;
+    t_blockIdx = ctx.bidx;
+    const unsigned long long fp = reinterpret_cast<unsigned long long>(&body);
+    for (int t = 0; t < T; t++) {
+        Lane& l = ctx.lanes[t];
+        l.tidx = uint3_emu{(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
+        l.lane = t & 63;
+        l.wave = t >> 6;
+        getcontext(&l.ctx);
+        l.ctx.uc_stack.ss_sp = stacks.data() + (size_t)t * kStackBytes;
+        l.ctx.uc_stack.ss_size = kStackBytes;
+        l.ctx.uc_link = nullptr;
+        makecontext(&l.ctx, reinterpret_cast<void (*)()>(&Tramp<F>::entry), 2, (unsigned)(fp & 0xffffffffu), (unsigned)(fp >> 32));
+    }
+    while (ctx.live > 0) {
+        for (int t = 0; t < T; t++) {
+            Lane& l = ctx.lanes[t];
+            if (l.done) continue;
+            ctx.cur = t;
+            t_threadIdx = l.tidx;
+            t_lane = l.lane;
+            t_wave = l.wave;
+            swapcontext(&ctx.sched, &l.ctx);
+        }
+    }
+    t_block = nullptr;
+}
+template <class F> void run_grid(const char*, dim3 grid, dim3 block, F&& body) {
+    g_blockDim = block;
+    g_gridDim = grid;
+    const unsigned long long nblocks = (unsigned long long)grid.x * grid.y * grid.z;
+    std::atomic<unsigned long long> next{0};
+    auto worker = [&]() {
+        std::vector<char> stacks;
+        for (;;) {
+            unsigned long long i = next.fetch_add(1);
+            if (i >= nblocks) break;
+            unsigned bx = (unsigned)(i % grid.x), by = (unsigned)((i / grid.x) % grid.y), bz = (unsigned)(i / ((unsigned long long)grid.x * grid.y));
+            F local = body;                      // per-OS-thread copy of the launch closure
+            run_block(local, block, bx, by, bz, stacks);
+        }
+    };
+    unsigned nthreads = std::min<unsigned long long>(nblocks, std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+    if (nthreads <= 1) { worker(); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthreads; t++) th.emplace_back(worker);
+    for (auto& x : th) x.join();
 }
 }
 

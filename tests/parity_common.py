@@ -103,4 +103,5 @@ def run_slam_sequence(cfg, n_frames, batch, literal, noise_amp=2, per_frame_chec
             stats["updates"] += int((ga == 1).sum()); stats["augments"] += int((ga == 0).sum()); stats["stationary"] += int((ga == 2).sum())
         stats["frames"] += nb
     assert np.array_equal(o.landmark_ids(), ctx.get_landmark_ids()), "landmark id table differs"
+    stats["landmarks"] = len(ctx.get_landmark_ids())
     return stats, ctx, o
