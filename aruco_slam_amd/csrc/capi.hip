@@ -22,13 +22,16 @@ enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_
 const char* kProfNames[P_COUNT] = {"k_threshold", "k_trace", "k_quads", "k_assemble", "k_identify", "k_pose",
                                    "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update"};
 
-struct ProfSpan { int id; hipEvent_t a, b; };
+struct ProfSpan { int id; hipEvent_t a, b; hipStream_t st; };
 
 } // namespace
 
 struct aslam_ctx {
     aslam_init init{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // detection + pose (batched over frames)
+    hipStream_t stream_ekf = nullptr;     // EKF chain (sequential over frames); overlaps the next batch's detection
+    hipEvent_t ev_detect = nullptr, ev_ekf = nullptr;
+    int ekf_first = 0, ekf_count = 0;     // slots the in-flight EKF chain still reads
     std::string err;
     bool have_cam = false;
     CamParams cam{};
@@ -124,18 +127,19 @@ void make_dict_aruco_original(std::vector<unsigned long long>& codes, std::vecto
     }
 }
 
-void prof_begin(aslam_ctx* c, int id) {
+void prof_begin(aslam_ctx* c, int id, hipStream_t st) {
     if (!c->prof_on) return;
     ProfSpan s;
     s.id = id;
+    s.st = st;
     hipEventCreate(&s.a);
     hipEventCreate(&s.b);
-    hipEventRecord(s.a, c->stream);
+    hipEventRecord(s.a, st);
     c->spans.push_back(s);
 }
 void prof_end(aslam_ctx* c) {
     if (!c->prof_on) return;
-    hipEventRecord(c->spans.back().b, c->stream);
+    hipEventRecord(c->spans.back().b, c->spans.back().st);
 }
 void prof_collect(aslam_ctx* c) {
     for (ProfSpan& s : c->spans) {
@@ -195,6 +199,10 @@ int run_detect(aslam_ctx* c, int first, int count) {
     const bool alias_gray = c->channels == 1;              // staged gray frames are tight: the detector reads them in place
     c->last_first = first;
     c->last_count = count;
+    if (c->ekf_count > 0 && first < c->ekf_first + c->ekf_count && c->ekf_first < first + count) {
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_ekf, 0));   // an EKF chain in flight still reads observations of these slots
+        c->ekf_count = 0;
+    }
     for (int f0 = first; f0 < first + count; f0 += max_frames_per_call()) {
         const int nf = std::min(max_frames_per_call(), first + count - f0);
         HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned), st));       // queue heads and work count; the overflow mask is sticky
@@ -208,59 +216,68 @@ int run_detect(aslam_ctx* c, int first, int count) {
         unsigned* starts = c->d_starts + (size_t)f0 * g.cap_starts;
         ContourRec* contours = c->d_contours + (size_t)f0 * g.cap_contours;
         unsigned* points = c->d_points + (size_t)f0 * g.cap_points;
-        prof_begin(c, P_THRESH);
+        prof_begin(c, P_THRESH, st);
         launch_threshold(st, in, c->channels, c->in_frame_bytes, (size_t)g.cols * c->channels, nf,
                          alias_gray ? nullptr : c->d_gray + (size_t)f0 * frame_px, nbr, g, starts, c->d_nstarts + f0, c->d_ctr);
         prof_end(c);
-        prof_begin(c, P_TRACE);
+        prof_begin(c, P_TRACE, st);
         launch_prefix(st, nf, c->d_nstarts + f0, g.cap_starts, 64u, c->d_pre_trace);
         launch_trace(st, c->nwaves, nbr, g, nf, starts, c->d_nstarts + f0, c->d_pre_trace, c->d_ctr, contours, c->d_ncontours + f0,
                      points, c->d_npoints + f0);
         prof_end(c);
-        prof_begin(c, P_QUADS);
+        prof_begin(c, P_QUADS, st);
         launch_prefix(st, nf, c->d_ncontours + f0, g.cap_contours, 1u, c->d_pre_quads);
         launch_quads(st, c->nwaves, g, nf, c->d_ctr, contours, c->d_ncontours + f0, c->d_pre_quads, points,
                      c->d_cands + (size_t)f0 * kCandMax, c->d_ncand + f0);
         prof_end(c);
-        prof_begin(c, P_ASSEMBLE);
+        prof_begin(c, P_ASSEMBLE, st);
         launch_assemble(st, nf, g, c->d_ctr, c->d_cands + (size_t)f0 * kCandMax, c->d_ncand + f0,
                         c->d_finals + (size_t)f0 * kCandMax, c->d_nfinal + f0, c->d_work);
         prof_end(c);
-        prof_begin(c, P_IDENTIFY);
+        prof_begin(c, P_IDENTIFY, st);
         launch_identify(st, c->nwaves, g, c->d_ctr, gray, c->d_finals + (size_t)f0 * kCandMax, c->d_work, c->d_dict);
         prof_end(c);
-        prof_begin(c, P_POSE);
+        prof_begin(c, P_POSE, st);
         launch_pose(st, nf, c->d_finals + (size_t)f0 * kCandMax, c->d_nfinal + f0, c->d_markers + (size_t)f0 * kMarkerMax,
                     c->d_nmarkers + f0, c->d_obs + (size_t)f0 * kMarkerMax, c->cam, c->sp, c->d_ctr);
         prof_end(c);
     }
+    HIP_TRY(c, hipEventRecord(c->ev_detect, st));
     HIP_TRY(c, hipGetLastError());
     return ASLAM_OK;
 }
 
 int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool do_predict) {
-    hipStream_t st = c->stream;
-    prof_begin(c, P_EKF_PLAN);
+    hipStream_t st = c->stream_ekf;
+    prof_begin(c, P_EKF_PLAN, st);
     launch_ekf_plan(st, c->ekf, c->sp, wl, wr, dt, do_predict ? 1 : 0, c->d_obs + (size_t)slot * kMarkerMax, c->d_nmarkers + slot, c->d_ctr);
     prof_end(c);
-    prof_begin(c, P_EKF_GATHER);
+    prof_begin(c, P_EKF_GATHER, st);
     launch_ekf_gather(st, c->ekf);
     prof_end(c);
-    prof_begin(c, P_EKF_SMALL);
+    prof_begin(c, P_EKF_SMALL, st);
     launch_ekf_small(st, c->ekf);
     prof_end(c);
-    prof_begin(c, P_EKF_T);
+    prof_begin(c, P_EKF_T, st);
     launch_ekf_T(st, c->ekf);
     prof_end(c);
-    prof_begin(c, P_EKF_UPDATE);
+    prof_begin(c, P_EKF_UPDATE, st);
     launch_ekf_update(st, c->ekf);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return ASLAM_OK;
 }
 
-int sync_and_check(aslam_ctx* c) {
+int sync_streams(aslam_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream_ekf));
+    c->ekf_count = 0;
+    return ASLAM_OK;
+}
+
+int sync_and_check(aslam_ctx* c) {
+    int rs = sync_streams(c);
+    if (rs) return rs;
     prof_collect(c);
     Counters h{};
     HIP_TRY(c, hipMemcpy(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
@@ -317,6 +334,9 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     const size_t px = (size_t)init->max_rows * init->max_cols;
     const size_t pitch = ((size_t)init->max_cols + 63) / 64 * 64;
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+    ok = ok && hipStreamCreate(&c->stream_ekf) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_detect, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_ekf, hipEventDisableTiming) == hipSuccess;
     ok = ok && dalloc(&c->d_in, px * 3 * B) == hipSuccess;
     ok = ok && dalloc(&c->d_gray, px * B) == hipSuccess;
     ok = ok && dalloc(&c->d_nbr, (size_t)kScales * init->max_rows * pitch * B) == hipSuccess;
@@ -360,6 +380,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
 void aslam_destroy(aslam_ctx* c) {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream_ekf) hipStreamSynchronize(c->stream_ekf);
     prof_collect(c);
     hipFree(c->d_in); hipFree(c->d_gray); hipFree(c->d_nbr); hipFree(c->d_starts); hipFree(c->d_ctr);
     hipFree(c->d_nstarts); hipFree(c->d_ncontours); hipFree(c->d_npoints); hipFree(c->d_pre_trace); hipFree(c->d_pre_quads);
@@ -367,7 +388,10 @@ void aslam_destroy(aslam_ctx* c) {
     hipFree(c->d_nfinal); hipFree(c->d_work); hipFree(c->d_dict); hipFree(c->d_markers); hipFree(c->d_nmarkers);
     hipFree(c->d_obs); hipFree(c->d_enc); hipFree(c->d_synth);
     ekf_free(c->ekf);
+    if (c->ev_detect) hipEventDestroy(c->ev_detect);
+    if (c->ev_ekf) hipEventDestroy(c->ev_ekf);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream_ekf) hipStreamDestroy(c->stream_ekf);
     delete c;
 }
 
@@ -421,6 +445,7 @@ int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
     if (r) return r;
     if (with_ekf) {
         if (c->enc_host.size() < (size_t)3 * (first + count)) return fail(c, ASLAM_E_STATE, "encoders not staged");
+        HIP_TRY(c, hipStreamWaitEvent(c->stream_ekf, c->ev_detect, 0));
         for (int i = 0; i < count; i++) {
             const double* e = &c->enc_host[(size_t)3 * (first + i)];
             // addEncoder semantics (aruco_slam.cpp:24-29): the very first sample only arms the filter
@@ -429,6 +454,9 @@ int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
             r = run_ekf_frame(c, first + i, e[0], e[1], e[2], predict);
             if (r) return r;
         }
+        HIP_TRY(c, hipEventRecord(c->ev_ekf, c->stream_ekf));
+        c->ekf_first = first;
+        c->ekf_count = count;
     }
     return ASLAM_OK;
 }
@@ -447,7 +475,7 @@ int aslam_add_encoder(aslam_ctx* c, double wl, double wr, double t_now) {
     }
     double dt = t_now - c->last_time;        // aruco_slam.cpp:31-32
     c->last_time = t_now;
-    launch_ekf_predict_only(c->stream, c->ekf, c->sp, wl, wr, dt);
+    launch_ekf_predict_only(c->stream_ekf, c->ekf, c->sp, wl, wr, dt);
     HIP_TRY(c, hipGetLastError());
     return ASLAM_OK;
 }
@@ -459,6 +487,7 @@ int aslam_add_image(aslam_ctx* c, const uint8_t* px, int rows, int cols, int cha
     if (r) return r;
     r = run_detect(c, 0, 1);
     if (r) return r;
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_ekf, c->ev_detect, 0));
     r = run_ekf_frame(c, 0, 0, 0, 0, false);
     if (r) return r;
     return sync_and_check(c);
@@ -466,7 +495,7 @@ int aslam_add_image(aslam_ctx* c, const uint8_t* px, int rows, int cols, int cha
 
 int aslam_get_state(aslam_ctx* c, int* N, double* mu, double* sigma) {
     if (!c || !N) return fail(c, ASLAM_E_INVALID, "null argument");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rs = sync_streams(c); if (rs) return rs; }
     int L = 0;
     HIP_TRY(c, hipMemcpy(&L, c->ekf.d_L, sizeof(int), hipMemcpyDeviceToHost));
     const int n = 3 + 3 * L;
@@ -486,7 +515,7 @@ int aslam_set_state(aslam_ctx* c, int N, const double* mu, const double* sigma, 
     const int L = (N - 3) / 3;
     if (L > c->ekf.max_landmarks) return fail(c, ASLAM_E_CAPACITY, "state larger than max_landmarks");
     if (L > 0 && !landmark_ids) return fail(c, ASLAM_E_INVALID, "landmark ids required");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rs = sync_streams(c); if (rs) return rs; }
     std::vector<double> tmp((size_t)c->ekf.ld * c->ekf.ld, 0.0);
     for (int col = 0; col < N; col++) std::memcpy(&tmp[(size_t)col * c->ekf.ld], sigma + (size_t)col * N, sizeof(double) * N);
     HIP_TRY(c, hipMemcpy(c->ekf.d_sigma, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -552,7 +581,7 @@ int aslam_get_slot_raw_observations(aslam_ctx* c, int slot, int* n_out, int* ids
 
 int aslam_get_observations(aslam_ctx* c, int* n_out, int* ids, int* idx, int* action, double* xyth, double* Rdiag) {
     if (!c || !n_out) return fail(c, ASLAM_E_INVALID, "null argument");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rs = sync_streams(c); if (rs) return rs; }
     int n = 0;
     HIP_TRY(c, hipMemcpy(&n, c->ekf.d_npop, sizeof(int), hipMemcpyDeviceToHost));
     std::vector<PopRec> h(n);
@@ -570,7 +599,7 @@ int aslam_get_observations(aslam_ctx* c, int* n_out, int* ids, int* idx, int* ac
 
 int aslam_get_landmark_ids(aslam_ctx* c, int* L, int* ids) {
     if (!c || !L) return fail(c, ASLAM_E_INVALID, "null argument");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rs = sync_streams(c); if (rs) return rs; }
     int n = 0;
     HIP_TRY(c, hipMemcpy(&n, c->ekf.d_L, sizeof(int), hipMemcpyDeviceToHost));
     *L = n;
@@ -610,11 +639,11 @@ int aslam_detect_batch(aslam_ctx* c, const uint8_t* frames, int nframes, int row
 
 int aslam_export_map(aslam_ctx* c, void* dst, int dst_is_device) {
     if (!c || !dst) return fail(c, ASLAM_E_INVALID, "null argument");
-    launch_ekf_export_map(c->stream, c->ekf);
+    launch_ekf_export_map(c->stream_ekf, c->ekf);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(dst, c->ekf.d_maprec, (size_t)ASLAM_MAP_RECORD_BYTES * c->ekf.max_landmarks,
-                              dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                              dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream_ekf));
+    HIP_TRY(c, hipStreamSynchronize(c->stream_ekf));
     return ASLAM_OK;
 }
 
@@ -705,14 +734,14 @@ int aslam_debug_get_candidates(aslam_ctx* c, int slot, int stage, int max, int* 
 int aslam_profile_enable(aslam_ctx* c, int on) { if (!c) return ASLAM_E_INVALID; c->prof_on = on != 0; return ASLAM_OK; }
 int aslam_profile_reset(aslam_ctx* c) {
     if (!c) return ASLAM_E_INVALID;
-    hipStreamSynchronize(c->stream);
+    sync_streams(c);
     prof_collect(c);
     for (int i = 0; i < P_COUNT; i++) { c->prof_calls[i] = 0; c->prof_ms[i] = 0; }
     return ASLAM_OK;
 }
 int aslam_profile_get(aslam_ctx* c, int max, const char** names, int* calls, double* total_ms) {
     if (!c) return ASLAM_E_INVALID;
-    hipStreamSynchronize(c->stream);
+    sync_streams(c);
     prof_collect(c);
     int n = std::min(max, (int)P_COUNT);
     for (int i = 0; i < n; i++) {

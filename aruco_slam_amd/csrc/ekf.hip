@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
                                                   Counters* ctr) {
     __shared__ double sH[9], sQ[9];
     __shared__ ObsRaw sObs[kMarkerMax];
+    __shared__ LastObs sLast[kMarkerMax];
     __shared__ int sHeap[kMarkerMax];          // heap of observation slots
     __shared__ int sIndex[kMarkerMax];         // aruco_index_ per slot (-1 new, -2 dropped by the gates)
     __shared__ int sOrder[kMarkerMax];         // pop order
@@ -255,14 +256,16 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     }
 
     // ---- already mapped (aruco_slam.cpp:108-207): every record is independent of the others (frozen mean, Q1) ----
-    const int nl = *E.d_nlast;
+    const int nl = min(*E.d_nlast, kMarkerMax);
+    for (int k = tid; k < nl; k += nt) sLast[k] = E.d_last[k];
+    __syncthreads();
     for (int q = nnew + tid; q < np; q += nt) {
         const ObsRaw o = sObs[sOrder[q]];
         // "stationary" test against the previous frame (aruco_slam.cpp:192-198): a no-op branch (quirk Q2)
         bool stationary = false;
         for (int k = 0; k < nl; k++)
-            if (E.d_last[k].id == o.id) {                                  // std::find: first with the same id
-                double d0 = E.d_last[k].z[0] - o.x, d1 = E.d_last[k].z[1] - o.y, d2 = E.d_last[k].z[2] - o.th;
+            if (sLast[k].id == o.id) {                                     // std::find: first with the same id
+                double d0 = sLast[k].z[0] - o.x, d1 = sLast[k].z[1] - o.y, d2 = sLast[k].z[2] - o.th;
                 stationary = sqrt(d0 * d0 + d1 * d1 + d2 * d2) < 0.01;     // NaN compares false (Q2/Q3)
                 break;
             }
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         lo.id = o.id; lo.pad = 0;
         if (sAction[q] == 1) { lo.z[0] = o.x; lo.z[1] = o.y; lo.z[2] = o.th; }
         else { lo.z[0] = lo.z[1] = lo.z[2] = nan(""); }
-        E.d_lastNext[q] = lo;
+        E.d_last[q] = lo;            // every thread finished reading the previous list (LDS copy) before the barrier above
         const int up = sUpdPos[q];
         if (up >= 0) {
             const int li = 3 + 3 * index;
@@ -311,9 +314,6 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
             E.d_upd[up] = u;
         }
     }
-    __syncthreads();
-    // the previous frame's list was read above by every thread; publish the new one for the next frame
-    for (int q = tid; q < np; q += nt) E.d_last[q] = E.d_lastNext[q];
     if (tid == 0) {
         *E.d_nlast = np;
         *E.d_npop = np;
@@ -458,98 +458,131 @@ __device__ void ekf_small_general(const EkfState& E, double* scratch /* >= 2*9*k
 // With the scalar LU A = L' U'' (no pivoting; A is an SPD innovation covariance), L_blk = L' diag(L'_ii)^-1, so
 //     nu = L' ze_hat ,  ze_hat_i = L'_ii^-1 ze_i ,  g = A^-1 nu ,  G = A^-1 .
 // A^-1 is formed by in-place Gauss-Jordan in LDS; the multipliers of the rows below each pivot are exactly L'.
-constexpr int kSmallMax = 96;            // 3m <= 96 (m <= 32 fused updates) runs out of LDS; larger frames use the general path
+constexpr int kSmallMax = 72;            // 3m <= 72 (m <= 24 fused updates) runs out of LDS; larger frames use the general path
+constexpr int SMT = 576;                 // threads: 64 columns x 9 row groups
 
-__global__ __launch_bounds__(512) void k_ekf_small(EkfState E) {
-    __shared__ double sA[kSmallMax * kSmallMax];
-    __shared__ double sLm[kSmallMax * kSmallMax];
-    __shared__ double sCol[kSmallMax], sRow[kSmallMax];
+__global__ __launch_bounds__(576) void k_ekf_small(EkfState E) {
+    __shared__ double sA0[kSmallMax * kSmallMax];     // ping
+    __shared__ double sA1[kSmallMax * kSmallMax];     // pong
+    __shared__ double sLm[kSmallMax * kSmallMax];     // LU multipliers L' (unit lower)
     __shared__ double sZe[kSmallMax], sNu[kSmallMax];
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x;
     const int m = *E.d_m;
     const int n3 = 3 * m;
     const int ld = E.ld;
-    if (n3 > kSmallMax) {                      // uniform branch
-        ekf_small_general(E, sA);
+    const int tc = tid & 63, tr = tid >> 6;            // column lane, row group (0..8)
+    if (n3 > kSmallMax) {                              // uniform branch
+        ekf_small_general(E, sA0);
     } else if (m > 0) {
         // A[(3i+a)][(3j+b)] = (V_i H_j^T)[a][b] + delta_ij R_i[a][b]   (aruco_slam.cpp:146: (Gx*sigma_)*Gx^T + Rk)
-        for (int p = tid; p < n3 * n3; p += nt) {
-            const int rr = p / n3, cc = p - rr * n3;
-            const int j = cc / 3, b = cc - 3 * j;
+        for (int c = tc; c < n3; c += 64) {
+            const int j = c / 3, bq = c - 3 * j;
             const UpdRec& u = E.d_upd[j];
-            const double* v = E.d_V + (size_t)rr * ld;
-            const double* g = &u.Gxm[b * 6];
-            double a = v[0] * g[0] + v[1] * g[1] + v[2] * g[2] + v[u.li] * g[3] + v[u.li + 1] * g[4] + v[u.li + 2] * g[5];
-            if (rr == cc) a += u.r[b];
-            sA[p] = a;
-            sLm[p] = (rr == cc) ? 1.0 : 0.0;
-        }
-        for (int r = tid; r < n3; r += nt) sZe[r] = E.d_upd[r / 3].ze[r % 3];
-        __syncthreads();
-        for (int k = 0; k < n3; k++) {
-            // snapshot pivot column and pivot row
-            for (int i = tid; i < 2 * n3; i += nt) {
-                if (i < n3) sCol[i] = sA[i * n3 + k];
-                else sRow[i - n3] = sA[k * n3 + (i - n3)];
+            const int li = u.li;
+            const double g0 = u.Gxm[bq * 6], g1 = u.Gxm[bq * 6 + 1], g2 = u.Gxm[bq * 6 + 2], g3 = u.Gxm[bq * 6 + 3],
+                         g4 = u.Gxm[bq * 6 + 4], g5 = u.Gxm[bq * 6 + 5];
+            const double rdiag = u.r[bq];
+            for (int r = tr; r < n3; r += 9) {
+                const double* v = E.d_V + (size_t)r * ld;
+                double a = v[0] * g0 + v[1] * g1 + v[2] * g2 + v[li] * g3 + v[li + 1] * g4 + v[li + 2] * g5;
+                if (r == c) a += rdiag;
+                sA0[r * n3 + c] = a;
+                sLm[r * n3 + c] = (r == c) ? 1.0 : 0.0;
             }
-            __syncthreads();
-            const double ip = 1.0 / sCol[k];
-            for (int p = tid; p < n3 * n3; p += nt) {
-                const int r = p / n3, c = p - r * n3;
-                const double rk = (c == k) ? 1.0 : sRow[c];        // pivot row with its pivot column replaced by e_k
-                if (r == k) {
-                    sA[p] = rk * ip;
-                } else {
-                    const double f = sCol[r];
-                    const double cur = (c == k) ? 0.0 : sA[p];
-                    sA[p] = cur - f * (rk * ip);
-                    if (c == k && r > k) sLm[p] = f * ip;          // LU multiplier L'[r][k]
+        }
+        if (tid < n3) sZe[tid] = E.d_upd[tid / 3].ze[tid % 3];
+        __syncthreads();
+        // in-place-style Gauss-Jordan inverse without pivoting, ping-pong between two LDS images: one barrier per pivot
+        double* cur = sA0;
+        double* nxt = sA1;
+        for (int k = 0; k < n3; k++) {
+            const double ip = 1.0 / cur[k * n3 + k];
+            for (int c = tc; c < n3; c += 64) {
+                const double rk = (c == k) ? 1.0 : cur[k * n3 + c];     // pivot row with its pivot column replaced by e_k
+                const double rkip = rk * ip;
+                for (int r = tr; r < n3; r += 9) {
+                    if (r == k) {
+                        nxt[r * n3 + c] = rkip;
+                    } else {
+                        const double f = cur[r * n3 + k];
+                        const double old = (c == k) ? 0.0 : cur[r * n3 + c];
+                        nxt[r * n3 + c] = old - f * rkip;
+                        if (c == k && r > k) sLm[r * n3 + k] = f * ip;     // LU multiplier L'[r][k]
+                    }
                 }
             }
             __syncthreads();
+            double* t = cur; cur = nxt; nxt = t;
         }
         // ze_hat_i = L'_ii^-1 ze_i (3x3 unit lower), nu = L' ze_hat
         if (tid < m) {
-            const int i = tid, o = 3 * i;
+            const int o = 3 * tid;
             double z0 = sZe[o];
             double z1 = sZe[o + 1] - sLm[(o + 1) * n3 + o] * z0;
             double z2 = sZe[o + 2] - sLm[(o + 2) * n3 + o] * z0 - sLm[(o + 2) * n3 + o + 1] * z1;
             sZe[o] = z0; sZe[o + 1] = z1; sZe[o + 2] = z2;
         }
         __syncthreads();
-        for (int r = tid; r < n3; r += nt) {
+        if (tid < n3) {
             double s = 0;
-            for (int c = 0; c <= r; c++) s += sLm[r * n3 + c] * sZe[c];
-            sNu[r] = s;
+            for (int c = 0; c <= tid; c++) s += sLm[tid * n3 + c] * sZe[c];
+            sNu[tid] = s;
         }
         __syncthreads();
-        for (int p = tid; p < n3 * n3; p += nt) E.d_G[p] = sA[p];
-        for (int r = tid; r < n3; r += nt) {
+        for (int p = tid; p < n3 * n3; p += SMT) E.d_G[p] = cur[p];
+        if (tid < n3) {
             double s = 0;
-            for (int c = 0; c < n3; c++) s += sA[r * n3 + c] * sNu[c];
-            E.d_g[r] = s;
+            for (int c = 0; c < n3; c++) s += cur[tid * n3 + c] * sNu[c];
+            E.d_g[tid] = s;
         }
     }
 }
 
-// ---- T = G V (3m x N) and mu += W g ------------------------------------------------------------------------
+// ---- T = G V (3m x N) and mu += W g : one workgroup per 64 columns, G and the V tile staged in LDS -----------
+constexpr int TKC = 32;                  // depth chunk of G / V staged per pass
+
 __global__ __launch_bounds__(256) void k_ekf_T(EkfState E) {
+    __shared__ double sG[64][TKC + 1];           // G[q0 + qq][p0 + pp]   (64 output rows per pass)
+    __shared__ double sV[TKC][64];               // V[p0 + pp][c0 + x]
     const int m = *E.d_m;
     const int n3 = 3 * m;
     const int N = 3 + 3 * (*E.d_L);
     const int ld = E.ld;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int q0 = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (m > 0 && c < N) {
-        for (int q = q0; q < n3; q += 4 * gridDim.y) {
-            double s = 0;
-            for (int p = 0; p < n3; p++) s += E.d_G[(size_t)q * n3 + p] * E.d_V[(size_t)p * ld + c];
-            E.d_T[(size_t)q * ld + c] = s;
+    const int c0 = blockIdx.x * 64;
+    const int x = threadIdx.x & 63, qg = threadIdx.x >> 6;          // column in tile, group of 16 output rows
+    if (m > 0 && c0 < N) {                                           // uniform per workgroup
+        for (int q0 = 0; q0 < n3; q0 += 64) {
+            double acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[j] = 0.0;
+            for (int p0 = 0; p0 < n3; p0 += TKC) {
+                for (int i = threadIdx.x; i < 64 * TKC; i += 256) {
+                    const int qq = i / TKC, pp = i - qq * TKC;
+                    sG[qq][pp] = (q0 + qq < n3 && p0 + pp < n3) ? E.d_G[(size_t)(q0 + qq) * n3 + p0 + pp] : 0.0;
+                    const int vp = i >> 6, vx = i & 63;
+                    sV[vp][vx] = (p0 + vp < n3 && c0 + vx < N) ? E.d_V[(size_t)(p0 + vp) * ld + c0 + vx] : 0.0;
+                }
+                __syncthreads();
+                const int pe = min(TKC, n3 - p0);
+                for (int pp = 0; pp < pe; pp++) {
+                    const double v = sV[pp][x];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) acc[j] += sG[qg * 16 + j][pp] * v;
+                }
+                __syncthreads();
+            }
+            if (c0 + x < N) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int q = q0 + qg * 16 + j;
+                    if (q < n3) E.d_T[(size_t)q * ld + c0 + x] = acc[j];
+                }
+            }
         }
-        if (q0 == 0) {
+        if (qg == 0 && c0 + x < N) {
             double s = 0;
-            for (int p = 0; p < n3; p++) s += E.d_Wt[(size_t)p * ld + c] * E.d_g[p];
-            E.d_mu[c] += s;                                        // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
+            for (int p = 0; p < n3; p++) s += E.d_Wt[(size_t)p * ld + c0 + x] * E.d_g[p];
+            E.d_mu[c0 + x] += s;                                   // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
         }
     }
 }
@@ -682,10 +715,10 @@ void launch_ekf_gather(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_gather, dim3((E.ld + 255) / 256, 32), dim3(256), 0, st, E);
 }
 void launch_ekf_small(hipStream_t st, const EkfState& E) {
-    hipLaunchKernelGGL(k_ekf_small, dim3(1), dim3(512), 0, st, E);
+    hipLaunchKernelGGL(k_ekf_small, dim3(1), dim3(SMT), 0, st, E);
 }
 void launch_ekf_T(hipStream_t st, const EkfState& E) {
-    hipLaunchKernelGGL(k_ekf_T, dim3((E.ld + 63) / 64, 16), dim3(256), 0, st, E);
+    hipLaunchKernelGGL(k_ekf_T, dim3((E.ld + 63) / 64), dim3(256), 0, st, E);
 }
 void launch_ekf_update(hipStream_t st, const EkfState& E) {
     const int t = (E.ld + UT - 1) / UT;
