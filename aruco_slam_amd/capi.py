@@ -73,6 +73,7 @@ _SIGS = {
     "aslam_debug_get_nbr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p]),
     "aslam_debug_get_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, _ip, _ip, _ip, _ip, _llp]),
     "aslam_debug_get_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _ip, _fp, _ip, _ip]),
+    "aslam_debug_inject_observations": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _dp, _dp]),
     "aslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aslam_profile_reset": (C.c_int, [C.c_void_p]),
     "aslam_profile_get": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_char_p), _ip, _dp]),
@@ -230,7 +231,13 @@ class Context:
         self._ck(self.lib.aslam_stage_encoders(self.h, int(slot0), int(wl.size), _ptr(wl, _dp), _ptr(wr, _dp), _ptr(dt, _dp)))
 
     def run_staged(self, first, count, with_ekf=True):
-        self._ck(self.lib.aslam_run_staged(self.h, int(first), int(count), 1 if with_ekf else 0))
+        """with_ekf: False/0 detection + pose only, True/1 full path, 2 EKF steps only (injected observations)"""
+        self._ck(self.lib.aslam_run_staged(self.h, int(first), int(count), int(with_ekf)))
+
+    def inject_observations(self, slot, ids, valid, xyth, Rdiag):
+        ids = np.ascontiguousarray(ids, dtype=np.int32); valid = np.ascontiguousarray(valid, dtype=np.int32)
+        xyth = np.ascontiguousarray(xyth, dtype=np.float64).reshape(-1, 3); Rdiag = np.ascontiguousarray(Rdiag, dtype=np.float64).reshape(-1, 3)
+        self._ck(self.lib.aslam_debug_inject_observations(self.h, int(slot), int(ids.size), _ptr(ids, _ip), _ptr(valid, _ip), _ptr(xyth, _dp), _ptr(Rdiag, _dp)))
 
     def sync(self):
         self._ck(self.lib.aslam_sync(self.h))

@@ -441,8 +441,12 @@ int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
     if (!c) return ASLAM_E_INVALID;
     int r = check_slot_range(c, first, count);
     if (r) return r;
-    r = run_detect(c, first, count);
-    if (r) return r;
+    if (with_ekf != 2) {                       // 2 = EKF only, on observations already present in the slots (tests)
+        r = run_detect(c, first, count);
+        if (r) return r;
+    } else {
+        HIP_TRY(c, hipEventRecord(c->ev_detect, c->stream));
+    }
     if (with_ekf) {
         if (c->enc_host.size() < (size_t)3 * (first + count)) return fail(c, ASLAM_E_STATE, "encoders not staged");
         HIP_TRY(c, hipStreamWaitEvent(c->stream_ekf, c->ev_detect, 0));
@@ -728,6 +732,25 @@ int aslam_debug_get_candidates(aslam_ctx* c, int slot, int stage, int max, int* 
             if (ids) ids[i] = h[i].id;
         }
     }
+    return ASLAM_OK;
+}
+
+int aslam_debug_inject_observations(aslam_ctx* c, int slot, int n, const int* ids, const int* valid, const double* xyth,
+                                    const double* Rdiag) {
+    if (!c || n < 0 || n > kMarkerMax || (n && (!ids || !valid || !xyth || !Rdiag))) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    int r = check_slot_range(c, slot, 1);
+    if (r) return r;
+    r = sync_streams(c);
+    if (r) return r;
+    std::vector<ObsRaw> h(n);
+    for (int i = 0; i < n; i++) {
+        h[i].id = ids[i]; h[i].valid = valid[i];
+        h[i].x = xyth[3 * i]; h[i].y = xyth[3 * i + 1]; h[i].th = xyth[3 * i + 2];
+        h[i].r[0] = Rdiag[3 * i]; h[i].r[1] = Rdiag[3 * i + 1]; h[i].r[2] = Rdiag[3 * i + 2];
+    }
+    unsigned un = (unsigned)n;
+    if (n) HIP_TRY(c, hipMemcpy(c->d_obs + (size_t)slot * kMarkerMax, h.data(), n * sizeof(ObsRaw), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_nmarkers + slot, &un, sizeof(unsigned), hipMemcpyHostToDevice));
     return ASLAM_OK;
 }
 

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     __shared__ int sOrder[kMarkerMax];         // pop order
     __shared__ int sAction[kMarkerMax];        // per popped observation
     __shared__ int sUpdPos[kMarkerMax];        // position in the fused update list (-1 = none)
-    __shared__ int sNPop, sL, sM, sNNew;
+    __shared__ int sNPop, sL, sM, sNNew, sDup;
     __shared__ double sG[9], sMM[9], sNew[3];
     __shared__ int sDoAug;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -135,10 +135,33 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         if (o.valid) index = (o.id >= 0 && o.id < kIdTableSize) ? E.d_id2idx[o.id] : -1;   // checkLandmark (aruco_slam.cpp:423-435)
         sIndex[i] = index;
     }
+    if (tid == 0) { sNNew = 0; sNPop = 0; sDup = 0; }
     __syncthreads();
-    if (tid == 0) {
+    for (int i = tid; i < nM; i += nt) {
+        if (sIndex[i] == -1) atomicAdd(&sNNew, 1);
+        if (sIndex[i] != -2) atomicAdd(&sNPop, 1);
+    }
+    __syncthreads();
+    if (sNNew == 0) {
+        // Steady state (every marker already mapped): all keys of the priority queue are distinct unless one id was
+        // detected twice, so the pop order is simply ascending landmark index -> rank in parallel.
+        for (int i = tid; i < nM; i += nt) {
+            const int ki = sIndex[i];
+            if (ki < 0) continue;
+            int rank = 0;
+            for (int j = 0; j < nM; j++) {
+                const int kj = sIndex[j];
+                rank += (kj >= 0 && kj < ki);
+                if (j != i && kj == ki) sDup = 1;
+            }
+            sOrder[rank] = i;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && (sNNew > 0 || sDup)) {
         // obs_.push(ob) in detection order (aruco_slam.cpp:369-373): libstdc++ std::priority_queue = push_heap
-        // with operator< inverted on aruco_index_ (aruco_slam.h:85-88): new markers (-1) first, then ascending index
+        // with operator< inverted on aruco_index_ (aruco_slam.h:85-88): new markers (-1) first, then ascending index;
+        // equal keys come out in heap order, which is reproduced by running the very same push_heap / pop_heap steps.
         int len = 0, nnew = 0;
         for (int i = 0; i < nM; i++) {
             if (sIndex[i] == -2) continue;
@@ -182,9 +205,8 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         }
         sNPop = np;
         sNNew = nnew;
-        sL = L0;
-        sM = 0;
     }
+    if (tid == 0) { sL = L0; sM = 0; }
     __syncthreads();
     const int np = sNPop;
     const int nnew = sNNew;
@@ -454,81 +476,102 @@ __device__ void ekf_small_general(const EkfState& E, double* scratch /* >= 2*9*k
 // In exact arithmetic the M sequential rank-3 corrections equal ONE batch correction with A = H Sigma0 H^T + blockdiag(R):
 // G = A^-1 (the matrix-inversion lemma needs no symmetry).  The reference, however, feeds every update the innovation
 // computed at the frozen pre-frame mean (quirk Q1) instead of the running one, i.e. the batch filter sees the pseudo
-// innovations nu_i = ze_i + sum_{j<i} (H_i K_j) ze_j = (L_blk ze)_i, with L_blk the block-unit-lower factor of A.
-// With the scalar LU A = L' U'' (no pivoting; A is an SPD innovation covariance), L_blk = L' diag(L'_ii)^-1, so
-//     nu = L' ze_hat ,  ze_hat_i = L'_ii^-1 ze_i ,  g = A^-1 nu ,  G = A^-1 .
-// A^-1 is formed by in-place Gauss-Jordan in LDS; the multipliers of the rows below each pivot are exactly L'.
-constexpr int kSmallMax = 72;            // 3m <= 72 (m <= 24 fused updates) runs out of LDS; larger frames use the general path
-constexpr int SMT = 576;                 // threads: 64 columns x 9 row groups
+// innovations nu_i = ze_i + sum_{j<i} (H_i K_j) ze_j.  Both come out of ONE block Gauss-Jordan sweep with 3x3 pivots,
+// which is the reference's own recursion: at step i the pivot block IS S_i = H_i Sigma_{i-1} H_i^T + R_i
+// (aruco_slam.cpp:146) and the block multiplier of a later row block r IS H_r K_i.  A^-1 is formed in LDS, ping-pong
+// between two images (one barrier per pivot block).
+constexpr int kSmallMax = 96;            // 3m <= 96 (m <= 32 fused updates) runs out of LDS; larger frames use the general path
+constexpr int SMT = 768;                 // threads: 96 columns x 8 row groups
+constexpr int SMR = 12;                  // rows per thread = kSmallMax / 8
 
-__global__ __launch_bounds__(576) void k_ekf_small(EkfState E) {
+__device__ __forceinline__ void inv3_cof(const double* P, int n3, double* o) {   // 3x3 inverse (cofactors); P has row stride n3
+    const double a = P[0], b = P[1], c = P[2], d = P[n3], e = P[n3 + 1], f = P[n3 + 2], g = P[2 * n3], h = P[2 * n3 + 1], i = P[2 * n3 + 2];
+    const double A = e * i - f * h, B = f * g - d * i, C = d * h - e * g;
+    const double id = 1.0 / (a * A + b * B + c * C);
+    o[0] = A * id; o[1] = (c * h - b * i) * id; o[2] = (b * f - c * e) * id;
+    o[3] = B * id; o[4] = (a * i - c * g) * id; o[5] = (c * d - a * f) * id;
+    o[6] = C * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * d) * id;
+}
+
+__global__ __launch_bounds__(768) void k_ekf_small(EkfState E) {
     __shared__ double sA0[kSmallMax * kSmallMax];     // ping
     __shared__ double sA1[kSmallMax * kSmallMax];     // pong
-    __shared__ double sLm[kSmallMax * kSmallMax];     // LU multipliers L' (unit lower)
     __shared__ double sZe[kSmallMax], sNu[kSmallMax];
     const int tid = threadIdx.x;
     const int m = *E.d_m;
     const int n3 = 3 * m;
     const int ld = E.ld;
-    const int tc = tid & 63, tr = tid >> 6;            // column lane, row group (0..8)
+    const int tc = tid % kSmallMax, tr = tid / kSmallMax;     // column, row group (0..7); rows r = tr + 8*i
     if (n3 > kSmallMax) {                              // uniform branch
         ekf_small_general(E, sA0);
     } else if (m > 0) {
         // A[(3i+a)][(3j+b)] = (V_i H_j^T)[a][b] + delta_ij R_i[a][b]   (aruco_slam.cpp:146: (Gx*sigma_)*Gx^T + Rk)
-        for (int c = tc; c < n3; c += 64) {
-            const int j = c / 3, bq = c - 3 * j;
+        if (tc < n3) {
+            const int j = tc / 3, bq = tc - 3 * j;
             const UpdRec& u = E.d_upd[j];
             const int li = u.li;
             const double g0 = u.Gxm[bq * 6], g1 = u.Gxm[bq * 6 + 1], g2 = u.Gxm[bq * 6 + 2], g3 = u.Gxm[bq * 6 + 3],
                          g4 = u.Gxm[bq * 6 + 4], g5 = u.Gxm[bq * 6 + 5];
             const double rdiag = u.r[bq];
-            for (int r = tr; r < n3; r += 9) {
-                const double* v = E.d_V + (size_t)r * ld;
-                double a = v[0] * g0 + v[1] * g1 + v[2] * g2 + v[li] * g3 + v[li + 1] * g4 + v[li + 2] * g5;
-                if (r == c) a += rdiag;
-                sA0[r * n3 + c] = a;
-                sLm[r * n3 + c] = (r == c) ? 1.0 : 0.0;
+            double v0[SMR], v1[SMR], v2[SMR], v3[SMR], v4[SMR], v5[SMR];
+#pragma unroll
+            for (int i = 0; i < SMR; i++) {                  // issue every load before the first use
+                const int r = tr + 8 * i;
+                const double* v = E.d_V + (size_t)(r < n3 ? r : 0) * ld;
+                v0[i] = v[0]; v1[i] = v[1]; v2[i] = v[2]; v3[i] = v[li]; v4[i] = v[li + 1]; v5[i] = v[li + 2];
+            }
+#pragma unroll
+            for (int i = 0; i < SMR; i++) {
+                const int r = tr + 8 * i;
+                if (r < n3) {
+                    double a = v0[i] * g0 + v1[i] * g1 + v2[i] * g2 + v3[i] * g3 + v4[i] * g4 + v5[i] * g5;
+                    if (r == tc) a += rdiag;
+                    sA0[r * n3 + tc] = a;
+                }
             }
         }
-        if (tid < n3) sZe[tid] = E.d_upd[tid / 3].ze[tid % 3];
+        if (tid < n3) { const double z = E.d_upd[tid / 3].ze[tid % 3]; sZe[tid] = z; sNu[tid] = z; }
         __syncthreads();
-        // in-place-style Gauss-Jordan inverse without pivoting, ping-pong between two LDS images: one barrier per pivot
         double* cur = sA0;
         double* nxt = sA1;
-        for (int k = 0; k < n3; k++) {
-            const double ip = 1.0 / cur[k * n3 + k];
-            for (int c = tc; c < n3; c += 64) {
-                const double rk = (c == k) ? 1.0 : cur[k * n3 + c];     // pivot row with its pivot column replaced by e_k
-                const double rkip = rk * ip;
-                for (int r = tr; r < n3; r += 9) {
-                    if (r == k) {
-                        nxt[r * n3 + c] = rkip;
-                    } else {
-                        const double f = cur[r * n3 + k];
-                        const double old = (c == k) ? 0.0 : cur[r * n3 + c];
-                        nxt[r * n3 + c] = old - f * rkip;
-                        if (c == k && r > k) sLm[r * n3 + k] = f * ip;     // LU multiplier L'[r][k]
+        for (int ib = 0; ib < m; ib++) {
+            const int k0 = 3 * ib;
+            if (tc < n3) {
+                double Pi[9];
+                inv3_cof(cur + k0 * n3 + k0, n3, Pi);                         // S_i^-1 (every thread, from LDS broadcast reads)
+                const bool cin = tc >= k0 && tc < k0 + 3;
+                // pivot rows at this column, with the pivot block column replaced by the identity
+                const double p0 = cin ? (tc == k0 ? 1.0 : 0.0) : cur[k0 * n3 + tc];
+                const double p1 = cin ? (tc == k0 + 1 ? 1.0 : 0.0) : cur[(k0 + 1) * n3 + tc];
+                const double p2 = cin ? (tc == k0 + 2 ? 1.0 : 0.0) : cur[(k0 + 2) * n3 + tc];
+                const double y0 = Pi[0] * p0 + Pi[1] * p1 + Pi[2] * p2;       // (S_i^-1 * pivot rows)[., tc]
+                const double y1 = Pi[3] * p0 + Pi[4] * p1 + Pi[5] * p2;
+                const double y2 = Pi[6] * p0 + Pi[7] * p1 + Pi[8] * p2;
+                const double z0 = sZe[k0], z1 = sZe[k0 + 1], z2 = sZe[k0 + 2];
+#pragma unroll
+                for (int i = 0; i < SMR; i++) {
+                    const int r = tr + 8 * i;
+                    if (r < n3) {
+                        if (r >= k0 && r < k0 + 3) {
+                            nxt[r * n3 + tc] = r == k0 ? y0 : (r == k0 + 1 ? y1 : y2);
+                        } else {
+                            const double f0 = cur[r * n3 + k0], f1 = cur[r * n3 + k0 + 1], f2 = cur[r * n3 + k0 + 2];
+                            const double old = cin ? 0.0 : cur[r * n3 + tc];
+                            nxt[r * n3 + tc] = old - (f0 * y0 + f1 * y1 + f2 * y2);
+                            if (tc == k0 && r > k0 + 2) {
+                                // block multiplier H_r K_i = F_r S_i^-1 : nu_r += (H_r K_i) ze_i
+                                const double m0 = f0 * Pi[0] + f1 * Pi[3] + f2 * Pi[6];
+                                const double m1 = f0 * Pi[1] + f1 * Pi[4] + f2 * Pi[7];
+                                const double m2 = f0 * Pi[2] + f1 * Pi[5] + f2 * Pi[8];
+                                sNu[r] += m0 * z0 + m1 * z1 + m2 * z2;
+                            }
+                        }
                     }
                 }
             }
             __syncthreads();
             double* t = cur; cur = nxt; nxt = t;
         }
-        // ze_hat_i = L'_ii^-1 ze_i (3x3 unit lower), nu = L' ze_hat
-        if (tid < m) {
-            const int o = 3 * tid;
-            double z0 = sZe[o];
-            double z1 = sZe[o + 1] - sLm[(o + 1) * n3 + o] * z0;
-            double z2 = sZe[o + 2] - sLm[(o + 2) * n3 + o] * z0 - sLm[(o + 2) * n3 + o + 1] * z1;
-            sZe[o] = z0; sZe[o + 1] = z1; sZe[o + 2] = z2;
-        }
-        __syncthreads();
-        if (tid < n3) {
-            double s = 0;
-            for (int c = 0; c <= tid; c++) s += sLm[tid * n3 + c] * sZe[c];
-            sNu[tid] = s;
-        }
-        __syncthreads();
         for (int p = tid; p < n3 * n3; p += SMT) E.d_G[p] = cur[p];
         if (tid < n3) {
             double s = 0;
@@ -544,6 +587,7 @@ constexpr int TKC = 32;                  // depth chunk of G / V staged per pass
 __global__ __launch_bounds__(256) void k_ekf_T(EkfState E) {
     __shared__ double sG[64][TKC + 1];           // G[q0 + qq][p0 + pp]   (64 output rows per pass)
     __shared__ double sV[TKC][64];               // V[p0 + pp][c0 + x]
+    __shared__ double sMu[4][64];
     const int m = *E.d_m;
     const int n3 = 3 * m;
     const int N = 3 + 3 * (*E.d_L);
@@ -551,16 +595,38 @@ __global__ __launch_bounds__(256) void k_ekf_T(EkfState E) {
     const int c0 = blockIdx.x * 64;
     const int x = threadIdx.x & 63, qg = threadIdx.x >> 6;          // column in tile, group of 16 output rows
     if (m > 0 && c0 < N) {                                           // uniform per workgroup
+        // mu += W g: 4 partial sums per column (strided over p), loads issued in bulk
+        {
+            double s = 0;
+            for (int p = qg; p < n3; p += 16) {
+                double w0 = (c0 + x < N) ? E.d_Wt[(size_t)p * ld + c0 + x] : 0.0, gg0 = E.d_g[p];
+                double w1 = (p + 4 < n3 && c0 + x < N) ? E.d_Wt[(size_t)(p + 4) * ld + c0 + x] : 0.0, gg1 = (p + 4 < n3) ? E.d_g[p + 4] : 0.0;
+                double w2 = (p + 8 < n3 && c0 + x < N) ? E.d_Wt[(size_t)(p + 8) * ld + c0 + x] : 0.0, gg2 = (p + 8 < n3) ? E.d_g[p + 8] : 0.0;
+                double w3 = (p + 12 < n3 && c0 + x < N) ? E.d_Wt[(size_t)(p + 12) * ld + c0 + x] : 0.0, gg3 = (p + 12 < n3) ? E.d_g[p + 12] : 0.0;
+                s += w0 * gg0 + w1 * gg1 + w2 * gg2 + w3 * gg3;
+            }
+            sMu[qg][x] = s;
+        }
         for (int q0 = 0; q0 < n3; q0 += 64) {
             double acc[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) acc[j] = 0.0;
             for (int p0 = 0; p0 < n3; p0 += TKC) {
-                for (int i = threadIdx.x; i < 64 * TKC; i += 256) {
+                double tg[8], tv[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {                        // all loads first
+                    const int i = threadIdx.x + 256 * k;
                     const int qq = i / TKC, pp = i - qq * TKC;
-                    sG[qq][pp] = (q0 + qq < n3 && p0 + pp < n3) ? E.d_G[(size_t)(q0 + qq) * n3 + p0 + pp] : 0.0;
+                    tg[k] = (q0 + qq < n3 && p0 + pp < n3) ? E.d_G[(size_t)(q0 + qq) * n3 + p0 + pp] : 0.0;
                     const int vp = i >> 6, vx = i & 63;
-                    sV[vp][vx] = (p0 + vp < n3 && c0 + vx < N) ? E.d_V[(size_t)(p0 + vp) * ld + c0 + vx] : 0.0;
+                    tv[k] = (p0 + vp < n3 && c0 + vx < N) ? E.d_V[(size_t)(p0 + vp) * ld + c0 + vx] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = threadIdx.x + 256 * k;
+                    const int qq = i / TKC, pp = i - qq * TKC;
+                    sG[qq][pp] = tg[k];
+                    sV[i >> 6][i & 63] = tv[k];
                 }
                 __syncthreads();
                 const int pe = min(TKC, n3 - p0);
@@ -579,11 +645,8 @@ __global__ __launch_bounds__(256) void k_ekf_T(EkfState E) {
                 }
             }
         }
-        if (qg == 0 && c0 + x < N) {
-            double s = 0;
-            for (int p = 0; p < n3; p++) s += E.d_Wt[(size_t)p * ld + c0 + x] * E.d_g[p];
-            E.d_mu[c0 + x] += s;                                   // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
-        }
+        if (qg == 0 && c0 + x < N)
+            E.d_mu[c0 + x] += (sMu[0][x] + sMu[1][x]) + (sMu[2][x] + sMu[3][x]);     // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
     }
 }
 
@@ -602,15 +665,29 @@ __global__ __launch_bounds__(256) void k_ekf_update(EkfState E) {
     const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6;         // row in tile, group of 16 columns
     const bool active = m > 0 && r0 < N && c0 < N;                  // uniform per workgroup
     if (active) {
-        double acc[16];
+        double acc[16], sig[16];
+        const int r = r0 + tr;
 #pragma unroll
-        for (int j = 0; j < 16; j++) acc[j] = 0.0;
+        for (int j = 0; j < 16; j++) {                               // the Sigma tile is fetched while the products are formed
+            const int c = c0 + tc * 16 + j;
+            acc[j] = 0.0;
+            sig[j] = (r < N && c < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
+        }
         for (int p0 = 0; p0 < n3; p0 += UK) {
-            for (int i = threadIdx.x; i < UK * UT; i += 256) {
-                const int pp = i / UT, x = i - pp * UT;
+            double tw[8], tt[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = threadIdx.x + 256 * k;
+                const int pp = i >> 6, x = i & 63;
                 const int p = p0 + pp;
-                sW[pp][x] = (p < n3 && r0 + x < N) ? E.d_Wt[(size_t)p * ld + r0 + x] : 0.0;
-                sT[pp][x] = (p < n3 && c0 + x < N) ? E.d_T[(size_t)p * ld + c0 + x] : 0.0;
+                tw[k] = (p < n3 && r0 + x < N) ? E.d_Wt[(size_t)p * ld + r0 + x] : 0.0;
+                tt[k] = (p < n3 && c0 + x < N) ? E.d_T[(size_t)p * ld + c0 + x] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = threadIdx.x + 256 * k;
+                sW[i >> 6][i & 63] = tw[k];
+                sT[i >> 6][i & 63] = tt[k];
             }
             __syncthreads();
             const int pe = min(UK, n3 - p0);
@@ -621,12 +698,11 @@ __global__ __launch_bounds__(256) void k_ekf_update(EkfState E) {
             }
             __syncthreads();
         }
-        const int r = r0 + tr;
         if (r < N) {
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int c = c0 + tc * 16 + j;
-                if (c < N) E.d_sigma[(size_t)c * ld + r] -= acc[j];
+                if (c < N) E.d_sigma[(size_t)c * ld + r] = sig[j] - acc[j];
             }
         }
     }

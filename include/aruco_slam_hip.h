@@ -90,7 +90,7 @@ int aslam_get_landmark_ids(aslam_ctx* ctx, int* L, int* ids);
 /* ---- device-resident stream API (throughput path: frames staged once in HBM) -------------------------
  * aslam_stage_frames uploads nframes tightly packed frames into slots [slot0, slot0+nframes);
  * aslam_stage_encoders stores, per slot, the encoder sample (wl, wr, dt) that precedes that frame;
- * aslam_run_staged(first, count, with_ekf) then runs, entirely on the device and asynchronously on the context's
+ * aslam_run_staged(first, count, with_ekf) then runs (with_ekf: 0 detection+pose only, 1 full path, 2 EKF steps only), entirely on the device and asynchronously on the context's
  * stream: detection + pose for all `count` frames batched, followed (with_ekf != 0) by `count` sequential
  * addEncoder(dt) + addImage EKF steps.  aslam_sync waits and reports device-side overflow. */
 int aslam_stage_frames(aslam_ctx* ctx, int slot0, const uint8_t* frames, int nframes, int rows, int cols,
@@ -121,6 +121,11 @@ int aslam_debug_get_contours(aslam_ctx* ctx, int slot, int scale, int max_contou
                              int* n_contours, int* sizes, int* keys, int* points_xy, long long* n_points);
 int aslam_debug_get_candidates(aslam_ctx* ctx, int slot, int stage /*0 quads (unordered), 2 final*/, int max,
                                int* n, float* corners, int* sizes, int* ids);
+/* overwrite a slot's per-marker observations (id, passed-the-gates flag, (x,y,theta), diag R); together with
+ * aslam_run_staged(..., with_ekf = 2) = "EKF steps only" this replays recorded observation sequences through the
+ * device EKF without the detector (tests/test_ekf_golden.py). */
+int aslam_debug_inject_observations(aslam_ctx* ctx, int slot, int n, const int* ids, const int* valid, const double* xyth,
+                                    const double* Rdiag);
 /* HIP-event timing of each kernel family on the context's stream, accumulated since the last reset:
  * names[i] (static strings), calls[i], total_ms[i]; returns the number of entries. */
 int aslam_profile_enable(aslam_ctx* ctx, int on);
