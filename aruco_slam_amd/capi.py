@@ -33,6 +33,7 @@ class AslamInit(C.Structure):
         ("max_rows", C.c_int), ("max_cols", C.c_int),
         ("max_batch", C.c_int),
         ("persistent_waves", C.c_int),
+        ("max_updates_per_frame", C.c_int),
         ("cap_starts_per_frame", C.c_uint),
         ("cap_contours_per_frame", C.c_uint),
         ("cap_points_per_frame", C.c_uint),

@@ -18,9 +18,9 @@ using namespace aslam;
 namespace {
 
 enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
-              P_EKF_T, P_EKF_UPDATE, P_COUNT };
+              P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_COUNT };
 const char* kProfNames[P_COUNT] = {"k_threshold", "k_trace", "k_quads", "k_assemble", "k_identify", "k_pose",
-                                   "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update"};
+                                   "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update", "k_ekf_mid", "k_ekf_apply"};
 
 struct ProfSpan { int id; hipEvent_t a, b; hipStream_t st; };
 
@@ -249,21 +249,32 @@ int run_detect(aslam_ctx* c, int first, int count) {
 
 int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool do_predict) {
     hipStream_t st = c->stream_ekf;
+    const bool fast = c->init.max_updates_per_frame <= ekf_fast_max_updates();
     prof_begin(c, P_EKF_PLAN, st);
-    launch_ekf_plan(st, c->ekf, c->sp, wl, wr, dt, do_predict ? 1 : 0, c->d_obs + (size_t)slot * kMarkerMax, c->d_nmarkers + slot, c->d_ctr);
+    launch_ekf_plan(st, c->ekf, c->sp, wl, wr, dt, do_predict ? 1 : 0, c->d_obs + (size_t)slot * kMarkerMax, c->d_nmarkers + slot, c->d_ctr,
+                    fast ? ekf_fast_max_updates() : kMarkerMax);
     prof_end(c);
-    prof_begin(c, P_EKF_GATHER, st);
-    launch_ekf_gather(st, c->ekf);
-    prof_end(c);
-    prof_begin(c, P_EKF_SMALL, st);
-    launch_ekf_small(st, c->ekf);
-    prof_end(c);
-    prof_begin(c, P_EKF_T, st);
-    launch_ekf_T(st, c->ekf);
-    prof_end(c);
-    prof_begin(c, P_EKF_UPDATE, st);
-    launch_ekf_update(st, c->ekf);
-    prof_end(c);
+    if (fast) {
+        prof_begin(c, P_EKF_MID, st);
+        launch_ekf_mid(st, c->ekf);
+        prof_end(c);
+        prof_begin(c, P_EKF_APPLY, st);
+        launch_ekf_apply(st, c->ekf);
+        prof_end(c);
+    } else {
+        prof_begin(c, P_EKF_GATHER, st);
+        launch_ekf_gather(st, c->ekf);
+        prof_end(c);
+        prof_begin(c, P_EKF_SMALL, st);
+        launch_ekf_small(st, c->ekf);
+        prof_end(c);
+        prof_begin(c, P_EKF_T, st);
+        launch_ekf_T(st, c->ekf);
+        prof_end(c);
+        prof_begin(c, P_EKF_UPDATE, st);
+        launch_ekf_update(st, c->ekf);
+        prof_end(c);
+    }
     HIP_TRY(c, hipGetLastError());
     return ASLAM_OK;
 }
@@ -285,7 +296,7 @@ int sync_and_check(aslam_ctx* c) {
         unsigned zero = 0;
         hipMemcpy(&c->d_ctr->overflow, &zero, sizeof(unsigned), hipMemcpyHostToDevice);
         char buf[256];
-        snprintf(buf, sizeof(buf), "device list overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 candidates, 16 markers, 32 landmarks)", h.overflow);
+        snprintf(buf, sizeof(buf), "device list overflow (mask 0x%x: 1 starts, 2 contours, 4 points, 8 candidates, 16 markers, 32 landmarks, 64 fused updates > max_updates_per_frame)", h.overflow);
         return fail(c, ASLAM_E_CAPACITY, buf);
     }
     return ASLAM_OK;
@@ -307,6 +318,7 @@ void aslam_default_init(aslam_init* i) {
     i->max_rows = 720; i->max_cols = 1280;
     i->max_batch = 1;
     i->persistent_waves = 0;
+    i->max_updates_per_frame = 24;
     i->cap_starts_per_frame = 0; i->cap_contours_per_frame = 0; i->cap_points_per_frame = 0;
 }
 
@@ -315,6 +327,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     *out = nullptr;
     if (init->markers_dictionary != 16) return ASLAM_E_INVALID;   // only DICT_ARUCO_ORIGINAL can be generated offline
     if (init->max_rows <= 0 || init->max_cols <= 0 || init->max_batch <= 0 || init->max_landmarks <= 0) return ASLAM_E_INVALID;
+    if (init->max_updates_per_frame <= 0 || init->max_updates_per_frame > kMarkerMax) return ASLAM_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || init->device_id >= ndev) return ASLAM_E_NO_DEVICE;
     if (hipSetDevice(init->device_id) != hipSuccess) return ASLAM_E_NO_DEVICE;
@@ -333,8 +346,10 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     const int B = c->max_batch;
     const size_t px = (size_t)init->max_rows * init->max_cols;
     const size_t pitch = ((size_t)init->max_cols + 63) / 64 * 64;
-    bool ok = hipStreamCreate(&c->stream) == hipSuccess;
-    ok = ok && hipStreamCreate(&c->stream_ekf) == hipSuccess;
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // the latency-bound EKF chain outranks the batched detection
+    bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&c->stream_ekf, hipStreamNonBlocking, prio_hi) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_detect, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_ekf, hipEventDisableTiming) == hipSuccess;
     ok = ok && dalloc(&c->d_in, px * 3 * B) == hipSuccess;

@@ -16,7 +16,7 @@ constexpr int kCellPx = 8;        // perspectiveRemovePixelPerCell (3.2.0 defaul
 
 // overflow / error bits reported by the device in Counters::overflow
 enum : unsigned {
-    kOvfStarts = 1u, kOvfContours = 2u, kOvfPoints = 4u, kOvfCands = 8u, kOvfMarkers = 16u, kOvfLandmarks = 32u,
+    kOvfStarts = 1u, kOvfContours = 2u, kOvfPoints = 4u, kOvfCands = 8u, kOvfMarkers = 16u, kOvfLandmarks = 32u, kOvfUpdates = 64u,
 };
 
 // Everything the detector kernels need to know about one batch (host-filled, passed by value).

@@ -51,7 +51,10 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks);
 void ekf_free(EkfState& E);
 void launch_ekf_predict_only(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt);
 void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int do_predict,
-                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr);
+                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr, int max_m);
+void launch_ekf_mid(hipStream_t st, const EkfState& E);
+void launch_ekf_apply(hipStream_t st, const EkfState& E);
+int ekf_fast_max_updates();
 void launch_ekf_gather(hipStream_t st, const EkfState& E);
 void launch_ekf_small(hipStream_t st, const EkfState& E);
 void launch_ekf_T(hipStream_t st, const EkfState& E);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_ekf_predict(EkfState E, SlamParams sp, 
 // ---- plan: predict + queue order + augment + update plan (one workgroup) -----------------------------------
 __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, double wl, double wr, double dt, int do_predict,
                                                   const ObsRaw* __restrict__ obs, const unsigned* __restrict__ n_markers,
-                                                  Counters* ctr) {
+                                                  Counters* ctr, int max_m) {
     __shared__ double sH[9], sQ[9];
     __shared__ ObsRaw sObs[kMarkerMax];
     __shared__ LastObs sLast[kMarkerMax];
@@ -297,6 +297,11 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     if (tid == 0) {
         int m = 0;
         for (int q = 0; q < np; q++) sUpdPos[q] = (q >= nnew && sAction[q] == 1) ? m++ : -1;
+        if (m > max_m) {                 // more fused updates than the configured chain handles: reported, never silent
+            atomicOr(&ctr->overflow, (unsigned)kOvfUpdates);
+            for (int q = 0; q < np; q++) sUpdPos[q] = -1;
+            m = 0;
+        }
         sM = m;
     }
     __syncthreads();
@@ -708,6 +713,264 @@ __global__ __launch_bounds__(256) void k_ekf_update(EkfState E) {
     }
 }
 
+// =============================================================================================================
+// Fast chain (frames with at most kFastM fused updates): plan -> k_ekf_mid -> k_ekf_apply.
+//   k_ekf_mid   workgroup 0 forms the innovation matrix from the 3+3m observed rows/columns of Sigma0 only
+//               (A = H Sigma0[S,S] H^T + R needs nothing else), inverts it by the block Gauss-Jordan sweep above and
+//               emits G, g; the other workgroups gather V = H Sigma0 and W^T concurrently (independent of G).
+//   k_ekf_apply one workgroup per 64x64 tile of Sigma: T_tile = G V_tile in LDS, Sigma_tile -= W_tile^T... T_tile, and
+//               mu += W g on the tile column 0.  Sigma is read once and written once per frame.
+// =============================================================================================================
+constexpr int kFastM = 24;               // fused updates per frame handled by the fast chain
+constexpr int kFastN3 = 3 * kFastM;      // 72
+constexpr int kFastNS = 3 + kFastN3;     // 75 observed state rows/columns
+constexpr int MIDT = 768;
+
+__global__ __launch_bounds__(768) void k_ekf_mid(EkfState E) {
+    __shared__ double sS[kFastNS * kFastNS];          // Sigma0[S,S]
+    __shared__ double sA0[kFastN3 * kFastNS];         // ping (also HP restricted to S)
+    __shared__ double sA1[kFastN3 * kFastN3];         // pong
+    __shared__ double sGx[kFastM * 18];
+    __shared__ double sR[kFastN3], sZe[kFastN3], sNu[kFastN3];
+    __shared__ int sLi[kFastM];
+    const int tid = threadIdx.x;
+    const int m = *E.d_m;
+    const int ld = E.ld;
+    if (m <= 0 || m > kFastM) return;                  // uniform (m > kFastM is reported by k_ekf_plan)
+    const int n3 = 3 * m, ns = 3 + n3;
+    if (blockIdx.x > 0) {
+        // ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns) ----
+        const int N = 3 + 3 * (*E.d_L);
+        const int ncg = (ld + MIDT - 1) / MIDT;
+        const int gb = blockIdx.x - 1;
+        const int t = (gb % ncg) * MIDT + tid;
+        const int slice = gb / ncg, nslices = (gridDim.x - 1) / ncg;
+        if (t < N) {
+            const double* col = E.d_sigma + (size_t)t * ld;
+            const double c0 = col[0], c1 = col[1], c2 = col[2];
+            const double r0 = E.d_sigma[t], r1 = E.d_sigma[(size_t)ld + t], r2 = E.d_sigma[(size_t)2 * ld + t];
+            for (int k = slice; k < m; k += nslices) {
+                const UpdRec& u = E.d_upd[k];
+                const int li = u.li;
+                const double l0 = col[li], l1 = col[li + 1], l2 = col[li + 2];
+                const double q0 = E.d_sigma[(size_t)li * ld + t], q1 = E.d_sigma[(size_t)(li + 1) * ld + t],
+                             q2 = E.d_sigma[(size_t)(li + 2) * ld + t];
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const double* g = &u.Gxm[a * 6];
+                    E.d_V[(size_t)(3 * k + a) * ld + t] = g[0] * c0 + g[1] * c1 + g[2] * c2 + g[3] * l0 + g[4] * l1 + g[5] * l2;
+                    E.d_Wt[(size_t)(3 * k + a) * ld + t] = r0 * g[0] + r1 * g[1] + r2 * g[2] + q0 * g[3] + q1 * g[4] + q2 * g[5];
+                }
+            }
+        }
+        return;
+    }
+    // ---- workgroup 0: innovation matrix, its inverse, pseudo-innovations ----
+    for (int i = tid; i < m * 18; i += MIDT) sGx[i] = E.d_upd[i / 18].Gxm[i % 18];
+    if (tid < m) sLi[tid] = E.d_upd[tid].li;
+    if (tid < n3) { sR[tid] = E.d_upd[tid / 3].r[tid % 3]; const double z = E.d_upd[tid / 3].ze[tid % 3]; sZe[tid] = z; sNu[tid] = z; }
+    __syncthreads();
+    {   // Sigma0[S,S], S = {0,1,2} + the observed landmark triples; loads issued in bulk
+        double tmp[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int p = tid + MIDT * k;
+            double v = 0.0;
+            if (p < ns * ns) {
+                const int a = p / ns, b = p - a * ns;
+                const int ra = a < 3 ? a : sLi[(a - 3) / 3] + (a - 3) % 3;
+                const int cb = b < 3 ? b : sLi[(b - 3) / 3] + (b - 3) % 3;
+                v = E.d_sigma[(size_t)cb * ld + ra];
+            }
+            tmp[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int p = tid + MIDT * k; if (p < ns * ns) sS[p] = tmp[k]; }
+    }
+    __syncthreads();
+    // HP restricted to S: HPs[(3i+a)][b] = sum_p Gxm_i[a][p] * Sigma0[c6_i(p)][S_b]      (Gx * sigma_, aruco_slam.cpp:146)
+    for (int p = tid; p < n3 * ns; p += MIDT) {
+        const int r = p / ns, b = p - r * ns;
+        const int i = r / 3, a = r - 3 * i;
+        const double* g = &sGx[i * 18 + a * 6];
+        const int lo = 3 + 3 * i;
+        sA0[r * ns + b] = g[0] * sS[b] + g[1] * sS[ns + b] + g[2] * sS[2 * ns + b] +
+                          g[3] * sS[lo * ns + b] + g[4] * sS[(lo + 1) * ns + b] + g[5] * sS[(lo + 2) * ns + b];
+    }
+    __syncthreads();
+    // A[(3i+a)][(3j+b)] = sum_q HPs[(3i+a)][c6_j(q)] * Gxm_j[b][q] + delta R        ((Gx*sigma_) * Gx^T + Rk)
+    for (int p = tid; p < n3 * n3; p += MIDT) {
+        const int r = p / n3, c = p - r * n3;
+        const int j = c / 3, b = c - 3 * j;
+        const double* g = &sGx[j * 18 + b * 6];
+        const double* h = &sA0[r * ns];
+        const int lo = 3 + 3 * j;
+        double a = h[0] * g[0] + h[1] * g[1] + h[2] * g[2] + h[lo] * g[3] + h[lo + 1] * g[4] + h[lo + 2] * g[5];
+        if (r == c) a += sR[r];
+        sA1[p] = a;
+    }
+    __syncthreads();
+    // block Gauss-Jordan with 3x3 pivots: pivot block i IS S_i = H_i Sigma_{i-1} H_i^T + R_i, multiplier IS H_r K_i
+    double* __restrict__ cur = sA1;
+    double* __restrict__ nxt = sA0;
+    const int tc = tid % 96, tr = tid / 96;                 // column, row group (0..7)
+    for (int ib = 0; ib < m; ib++) {
+        const int k0 = 3 * ib;
+        if (tc < n3) {
+            double Pi[9];
+            inv3_cof(cur + k0 * n3 + k0, n3, Pi);
+            const bool cin = tc >= k0 && tc < k0 + 3;
+            const double p0 = cin ? (tc == k0 ? 1.0 : 0.0) : cur[k0 * n3 + tc];
+            const double p1 = cin ? (tc == k0 + 1 ? 1.0 : 0.0) : cur[(k0 + 1) * n3 + tc];
+            const double p2 = cin ? (tc == k0 + 2 ? 1.0 : 0.0) : cur[(k0 + 2) * n3 + tc];
+            const double y0 = Pi[0] * p0 + Pi[1] * p1 + Pi[2] * p2;
+            const double y1 = Pi[3] * p0 + Pi[4] * p1 + Pi[5] * p2;
+            const double y2 = Pi[6] * p0 + Pi[7] * p1 + Pi[8] * p2;
+            const double z0 = sZe[k0], z1 = sZe[k0 + 1], z2 = sZe[k0 + 2];
+            double f0[9], f1[9], f2[9], od[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {                      // all LDS loads of this step first
+                const int r = tr + 8 * i;
+                const int rr = r < n3 ? r : 0;
+                f0[i] = cur[rr * n3 + k0]; f1[i] = cur[rr * n3 + k0 + 1]; f2[i] = cur[rr * n3 + k0 + 2];
+                od[i] = cur[rr * n3 + tc];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int r = tr + 8 * i;
+                if (r < n3) {
+                    if (r >= k0 && r < k0 + 3) {
+                        nxt[r * n3 + tc] = r == k0 ? y0 : (r == k0 + 1 ? y1 : y2);
+                    } else {
+                        nxt[r * n3 + tc] = (cin ? 0.0 : od[i]) - (f0[i] * y0 + f1[i] * y1 + f2[i] * y2);
+                        if (tc == k0 && r > k0 + 2) {
+                            const double m0 = f0[i] * Pi[0] + f1[i] * Pi[3] + f2[i] * Pi[6];
+                            const double m1 = f0[i] * Pi[1] + f1[i] * Pi[4] + f2[i] * Pi[7];
+                            const double m2 = f0[i] * Pi[2] + f1[i] * Pi[5] + f2[i] * Pi[8];
+                            sNu[r] += m0 * z0 + m1 * z1 + m2 * z2;       // nu_r += (H_r K_i) ze_i
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        double* t = cur; cur = nxt; nxt = t;
+    }
+    for (int p = tid; p < n3 * n3; p += MIDT) E.d_G[p] = cur[p];
+    if (tid < n3) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int c = 0;
+        for (; c + 3 < n3; c += 4) {
+            s0 += cur[tid * n3 + c] * sNu[c]; s1 += cur[tid * n3 + c + 1] * sNu[c + 1];
+            s2 += cur[tid * n3 + c + 2] * sNu[c + 2]; s3 += cur[tid * n3 + c + 3] * sNu[c + 3];
+        }
+        for (; c < n3; c++) s0 += cur[tid * n3 + c] * sNu[c];
+        E.d_g[tid] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+constexpr int APK = kFastN3;             // padded depth of the LDS images (72)
+
+__global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
+    __shared__ double sG[APK * APK];          // G, row stride APK, zero padded
+    __shared__ double sVW[APK][64];           // V tile, later the W^T tile
+    __shared__ double sT[APK][64];            // T tile = G V tile
+    __shared__ double sg[APK];
+    const int m = *E.d_m;
+    if (m <= 0 || m > kFastM) return;         // uniform
+    const int n3 = 3 * m;
+    const int N = 3 + 3 * (*E.d_L);
+    const int ld = E.ld;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    if (r0 >= N || c0 >= N) return;           // uniform
+    const int tid = threadIdx.x;
+    const int x = tid & 63, grp = tid >> 6;
+    const int r = r0 + x;
+
+    // Sigma tile (16 columns per thread) fetched first; it is only needed at the very end
+    double sig[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int c = c0 + grp * 16 + j;
+        sig[j] = (r < N && c < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
+    }
+    // G (zero padded to APK x APK) and the V tile
+    for (int i0 = 0; i0 < APK * APK; i0 += 256 * 8) {
+        double t8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + tid + 256 * k;
+            const int q = i / APK, pq = i - q * APK;
+            t8[k] = (i < APK * APK && q < n3 && pq < n3) ? E.d_G[(size_t)q * n3 + pq] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int i = i0 + tid + 256 * k; if (i < APK * APK) sG[i] = t8[k]; }
+    }
+    for (int i0 = 0; i0 < APK * 64; i0 += 256 * 6) {
+        double t6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = i0 + tid + 256 * k;
+            const int pq = i >> 6, xx = i & 63;
+            t6[k] = (pq < n3 && c0 + xx < N) ? E.d_V[(size_t)pq * ld + c0 + xx] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { const int i = i0 + tid + 256 * k; sVW[i >> 6][i & 63] = t6[k]; }
+    }
+    if (tid < APK) sg[tid] = tid < n3 ? E.d_g[tid] : 0.0;
+    __syncthreads();
+    // T tile: thread (x, grp) forms rows grp*18 .. grp*18+17 of column x
+    {
+        double acc[18];
+#pragma unroll
+        for (int j = 0; j < 18; j++) acc[j] = 0.0;
+        for (int pq = 0; pq < n3; pq += 2) {
+            const double v0 = sVW[pq][x], v1 = sVW[pq + 1][x];      // row n3 (if n3 is odd) is zero padded
+#pragma unroll
+            for (int j = 0; j < 18; j++) {
+                const double* gq = &sG[(grp * 18 + j) * APK + pq];
+                acc[j] += gq[0] * v0 + gq[1] * v1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 18; j++) sT[grp * 18 + j][x] = acc[j];
+    }
+    __syncthreads();
+    // W^T tile replaces the V tile
+    for (int i0 = 0; i0 < APK * 64; i0 += 256 * 6) {
+        double t6[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = i0 + tid + 256 * k;
+            const int pq = i >> 6, xx = i & 63;
+            t6[k] = (pq < n3 && r0 + xx < N) ? E.d_Wt[(size_t)pq * ld + r0 + xx] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { const int i = i0 + tid + 256 * k; sVW[i >> 6][i & 63] = t6[k]; }
+    }
+    __syncthreads();
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.0;
+    for (int pq = 0; pq < n3; pq++) {
+        const double w = sVW[pq][x];
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[j] += w * sT[pq][grp * 16 + j];
+    }
+    if (r < N) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int c = c0 + grp * 16 + j;
+            if (c < N) E.d_sigma[(size_t)c * ld + r] = sig[j] - acc[j];
+        }
+        if (blockIdx.y == 0 && grp == 0) {
+            double s0 = 0, s1 = 0;
+            for (int pq = 0; pq < n3; pq += 2) { s0 += sVW[pq][x] * sg[pq]; s1 += sVW[pq + 1][x] * sg[pq + 1]; }
+            E.d_mu[r] += s0 + s1;                                  // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ekf_export_map(EkfState E) {
     const int L = *E.d_L;
     const int ld = E.ld;
@@ -784,8 +1047,8 @@ void launch_ekf_predict_only(hipStream_t st, const EkfState& E, const SlamParams
     hipLaunchKernelGGL(k_ekf_predict, dim3(1), dim3(256), 0, st, E, sp, wl, wr, dt);
 }
 void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int do_predict,
-                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr) {
-    hipLaunchKernelGGL(k_ekf_plan, dim3(1), dim3(256), 0, st, E, sp, wl, wr, dt, do_predict, obs, n_markers, ctr);
+                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr, int max_m) {
+    hipLaunchKernelGGL(k_ekf_plan, dim3(1), dim3(256), 0, st, E, sp, wl, wr, dt, do_predict, obs, n_markers, ctr, max_m);
 }
 void launch_ekf_gather(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_gather, dim3((E.ld + 255) / 256, 32), dim3(256), 0, st, E);
@@ -800,6 +1063,15 @@ void launch_ekf_update(hipStream_t st, const EkfState& E) {
     const int t = (E.ld + UT - 1) / UT;
     hipLaunchKernelGGL(k_ekf_update, dim3(t, t), dim3(256), 0, st, E);
 }
+void launch_ekf_mid(hipStream_t st, const EkfState& E) {
+    const int ncg = (E.ld + MIDT - 1) / MIDT;
+    hipLaunchKernelGGL(k_ekf_mid, dim3(1 + ncg * 12), dim3(MIDT), 0, st, E);
+}
+void launch_ekf_apply(hipStream_t st, const EkfState& E) {
+    const int t = (E.ld + 63) / 64;
+    hipLaunchKernelGGL(k_ekf_apply, dim3(t, t), dim3(256), 0, st, E);
+}
+int ekf_fast_max_updates() { return kFastM; }
 void launch_ekf_export_map(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_export_map, dim3((E.max_landmarks + 255) / 256), dim3(256), 0, st, E);
 }

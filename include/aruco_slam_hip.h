@@ -48,6 +48,9 @@ typedef struct {
     int    max_rows, max_cols;           /* largest frame that will be handed over */
     int    max_batch;                    /* frames staged / processed per call of the *_staged functions */
     int    persistent_waves;             /* wavefronts of the work-queue kernels; 0 = default (2048) */
+    int    max_updates_per_frame;        /* EKF corrections fused per frame; <= 24 selects the 3-kernel fast chain,
+                                            larger values (up to 128) the general 5-kernel chain; exceeding it at run
+                                            time is reported as ASLAM_E_CAPACITY */
     unsigned cap_starts_per_frame;       /* 0 = defaults */
     unsigned cap_contours_per_frame;
     unsigned cap_points_per_frame;

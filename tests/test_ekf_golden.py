@@ -15,11 +15,11 @@ from oracle.ekf_literal import LiteralSlam
 GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ekf_literal_*.npz")))
 
 
-def replay(path, batch):
+def replay(path, batch, max_updates=24):
     g = np.load(path)
     nfr = int(g["n_frames"])
     r2c = g["r2c"]
-    ctx = capi.Context(max_rows=64, max_cols=64, max_batch=nfr, persistent_waves=4, max_landmarks=32,
+    ctx = capi.Context(max_rows=64, max_cols=64, max_batch=nfr, persistent_waves=4, max_landmarks=32, max_updates_per_frame=max_updates,
                        r2c_t=(float(r2c[0]), float(r2c[1]), 0.0))
     ctx.set_camera(g["K"], g["D"])
     # observation assembly (gates, covariance) in Python, independent of the device pose kernel
@@ -64,8 +64,20 @@ def test_device_ekf_replays_golden_batched(path):
     replay(path, batch=5)
 
 
+def test_device_ekf_general_chain():
+    """max_updates_per_frame > 24 selects the general 5-kernel chain (used by 50-marker frames)"""
+    replay(GOLDEN[2], batch=1, max_updates=64)
+
+
+def test_too_many_updates_is_reported():
+    with pytest.raises(capi.AslamError) as e:
+        replay(GOLDEN[2], batch=1, max_updates=4)
+    assert e.value.code == -4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
 def test_device_ekf_replays_golden_on_gpu(path):
     replay(path, batch=1)
     replay(path, batch=4)
+    replay(path, batch=3, max_updates=64)
