@@ -252,7 +252,7 @@ int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool 
     const bool fast = c->init.max_updates_per_frame <= ekf_fast_max_updates();
     prof_begin(c, P_EKF_PLAN, st);
     launch_ekf_plan(st, c->ekf, c->sp, wl, wr, dt, do_predict ? 1 : 0, c->d_obs + (size_t)slot * kMarkerMax, c->d_nmarkers + slot, c->d_ctr,
-                    fast ? ekf_fast_max_updates() : kMarkerMax);
+                    c->init.max_updates_per_frame);
     prof_end(c);
     if (fast) {
         prof_begin(c, P_EKF_MID, st);

@@ -723,21 +723,33 @@ __global__ __launch_bounds__(256) void k_ekf_update(EkfState E) {
 // =============================================================================================================
 constexpr int kFastM = 24;               // fused updates per frame handled by the fast chain
 constexpr int kFastN3 = 3 * kFastM;      // 72
-constexpr int kFastNS = 3 + kFastN3;     // 75 observed state rows/columns
-constexpr int MIDT = 768;
+constexpr int MIDT = 576;                // kFastM x kFastM: one thread per 3x3 block of the innovation matrix
 
-__global__ __launch_bounds__(768) void k_ekf_mid(EkfState E) {
-    __shared__ double sS[kFastNS * kFastNS];          // Sigma0[S,S]
-    __shared__ double sA0[kFastN3 * kFastNS];         // ping (also HP restricted to S)
-    __shared__ double sA1[kFastN3 * kFastN3];         // pong
-    __shared__ double sGx[kFastM * 18];
-    __shared__ double sR[kFastN3], sZe[kFastN3], sNu[kFastN3];
-    __shared__ int sLi[kFastM];
+__device__ __forceinline__ void inv3_reg(const double* P, double* o) {   // 3x3 inverse (cofactors), row-major
+    const double a = P[0], b = P[1], c = P[2], d = P[3], e = P[4], f = P[5], g = P[6], h = P[7], i = P[8];
+    const double A = e * i - f * h, B = f * g - d * i, C = d * h - e * g;
+    const double id = 1.0 / (a * A + b * B + c * C);
+    o[0] = A * id; o[1] = (c * h - b * i) * id; o[2] = (b * f - c * e) * id;
+    o[3] = B * id; o[4] = (a * i - c * g) * id; o[5] = (c * d - a * f) * id;
+    o[6] = C * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * d) * id;
+}
+__device__ __forceinline__ void mul3(const double* X, const double* Y, double* Z) {   // Z = X * Y (3x3 row-major)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Z[i * 3 + j] = X[i * 3] * Y[j] + X[i * 3 + 1] * Y[3 + j] + X[i * 3 + 2] * Y[6 + j];
+}
+
+__global__ __launch_bounds__(576) void k_ekf_mid(EkfState E) {
+    __shared__ double sRow[2][kFastM][9];             // pivot row blocks (ib, bj) of the current / next step
+    __shared__ double sCol[2][kFastM][9];             // pivot column blocks (bi, ib)
+    __shared__ double sZe[kFastN3], sNu[kFastN3];
+    __shared__ double sPart[kFastM][kFastM][3];
     const int tid = threadIdx.x;
     const int m = *E.d_m;
     const int ld = E.ld;
     if (m <= 0 || m > kFastM) return;                  // uniform (m > kFastM is reported by k_ekf_plan)
-    const int n3 = 3 * m, ns = 3 + n3;
+    const int n3 = 3 * m;
     if (blockIdx.x > 0) {
         // ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns) ----
         const int N = 3 + 3 * (*E.d_L);
@@ -765,107 +777,103 @@ __global__ __launch_bounds__(768) void k_ekf_mid(EkfState E) {
         }
         return;
     }
-    // ---- workgroup 0: innovation matrix, its inverse, pseudo-innovations ----
-    for (int i = tid; i < m * 18; i += MIDT) sGx[i] = E.d_upd[i / 18].Gxm[i % 18];
-    if (tid < m) sLi[tid] = E.d_upd[tid].li;
-    if (tid < n3) { sR[tid] = E.d_upd[tid / 3].r[tid % 3]; const double z = E.d_upd[tid / 3].ze[tid % 3]; sZe[tid] = z; sNu[tid] = z; }
-    __syncthreads();
-    {   // Sigma0[S,S], S = {0,1,2} + the observed landmark triples; loads issued in bulk
-        double tmp[8];
+    // ---- workgroup 0: thread (bi, bj) owns the 3x3 block (bi, bj) of A = H Sigma0 H^T + R in registers ----
+    const int bj = tid % kFastM, bi = tid / kFastM;
+    const bool act = bi < m && bj < m;
+    double A[9];
+    if (tid < n3) { const double z = E.d_upd[tid / 3].ze[tid % 3]; sZe[tid] = z; sNu[tid] = z; }
+    if (act) {
+        const UpdRec& ui = E.d_upd[bi];
+        const UpdRec& uj = E.d_upd[bj];
+        const int li = ui.li, lj = uj.li;
+        // the 6x6 block Sigma0[c6_i, c6_j] (c6 = robot triple + landmark triple), every load issued before the first use
+        double S[36];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int p = tid + MIDT * k;
-            double v = 0.0;
-            if (p < ns * ns) {
-                const int a = p / ns, b = p - a * ns;
-                const int ra = a < 3 ? a : sLi[(a - 3) / 3] + (a - 3) % 3;
-                const int cb = b < 3 ? b : sLi[(b - 3) / 3] + (b - 3) % 3;
-                v = E.d_sigma[(size_t)cb * ld + ra];
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const int r = p < 3 ? p : li + p - 3, c = q < 3 ? q : lj + q - 3;
+                S[p * 6 + q] = E.d_sigma[(size_t)c * ld + r];
             }
-            tmp[k] = v;
-        }
+        double Gi[18], Gj[18];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const int p = tid + MIDT * k; if (p < ns * ns) sS[p] = tmp[k]; }
+        for (int k = 0; k < 18; k++) { Gi[k] = ui.Gxm[k]; Gj[k] = uj.Gxm[k]; }
+        // (Gx * sigma_) * Gx^T + Rk   (aruco_slam.cpp:146)
+        double HP[18];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                double s = 0;
+#pragma unroll
+                for (int p = 0; p < 6; p++) s += Gi[a * 6 + p] * S[p * 6 + q];
+                HP[a * 6 + q] = s;
+            }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                double s = 0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) s += HP[a * 6 + q] * Gj[b * 6 + q];
+                A[a * 3 + b] = s;
+            }
+        if (bi == bj) { A[0] += ui.r[0]; A[4] += ui.r[1]; A[8] += ui.r[2]; }
+        if (bi == 0) { for (int k = 0; k < 9; k++) sRow[0][bj][k] = A[k]; }
+        if (bj == 0) { for (int k = 0; k < 9; k++) sCol[0][bi][k] = A[k]; }
     }
     __syncthreads();
-    // HP restricted to S: HPs[(3i+a)][b] = sum_p Gxm_i[a][p] * Sigma0[c6_i(p)][S_b]      (Gx * sigma_, aruco_slam.cpp:146)
-    for (int p = tid; p < n3 * ns; p += MIDT) {
-        const int r = p / ns, b = p - r * ns;
-        const int i = r / 3, a = r - 3 * i;
-        const double* g = &sGx[i * 18 + a * 6];
-        const int lo = 3 + 3 * i;
-        sA0[r * ns + b] = g[0] * sS[b] + g[1] * sS[ns + b] + g[2] * sS[2 * ns + b] +
-                          g[3] * sS[lo * ns + b] + g[4] * sS[(lo + 1) * ns + b] + g[5] * sS[(lo + 2) * ns + b];
-    }
-    __syncthreads();
-    // A[(3i+a)][(3j+b)] = sum_q HPs[(3i+a)][c6_j(q)] * Gxm_j[b][q] + delta R        ((Gx*sigma_) * Gx^T + Rk)
-    for (int p = tid; p < n3 * n3; p += MIDT) {
-        const int r = p / n3, c = p - r * n3;
-        const int j = c / 3, b = c - 3 * j;
-        const double* g = &sGx[j * 18 + b * 6];
-        const double* h = &sA0[r * ns];
-        const int lo = 3 + 3 * j;
-        double a = h[0] * g[0] + h[1] * g[1] + h[2] * g[2] + h[lo] * g[3] + h[lo + 1] * g[4] + h[lo + 2] * g[5];
-        if (r == c) a += sR[r];
-        sA1[p] = a;
-    }
-    __syncthreads();
-    // block Gauss-Jordan with 3x3 pivots: pivot block i IS S_i = H_i Sigma_{i-1} H_i^T + R_i, multiplier IS H_r K_i
-    double* __restrict__ cur = sA1;
-    double* __restrict__ nxt = sA0;
-    const int tc = tid % 96, tr = tid / 96;                 // column, row group (0..7)
+    // block Gauss-Jordan with 3x3 pivots: pivot block ib IS S_ib = H_ib Sigma_{ib-1} H_ib^T + R_ib, and the block multiplier
+    // F S_ib^-1 of a later row block IS H_bi K_ib (the reference's own recursion, aruco_slam.cpp:146,204)
     for (int ib = 0; ib < m; ib++) {
-        const int k0 = 3 * ib;
-        if (tc < n3) {
-            double Pi[9];
-            inv3_cof(cur + k0 * n3 + k0, n3, Pi);
-            const bool cin = tc >= k0 && tc < k0 + 3;
-            const double p0 = cin ? (tc == k0 ? 1.0 : 0.0) : cur[k0 * n3 + tc];
-            const double p1 = cin ? (tc == k0 + 1 ? 1.0 : 0.0) : cur[(k0 + 1) * n3 + tc];
-            const double p2 = cin ? (tc == k0 + 2 ? 1.0 : 0.0) : cur[(k0 + 2) * n3 + tc];
-            const double y0 = Pi[0] * p0 + Pi[1] * p1 + Pi[2] * p2;
-            const double y1 = Pi[3] * p0 + Pi[4] * p1 + Pi[5] * p2;
-            const double y2 = Pi[6] * p0 + Pi[7] * p1 + Pi[8] * p2;
-            const double z0 = sZe[k0], z1 = sZe[k0 + 1], z2 = sZe[k0 + 2];
-            double f0[9], f1[9], f2[9], od[9];
+        const int cb = ib & 1;
+        if (act) {
+            double P[9], Pi[9], Pr[9], F[9];
 #pragma unroll
-            for (int i = 0; i < 9; i++) {                      // all LDS loads of this step first
-                const int r = tr + 8 * i;
-                const int rr = r < n3 ? r : 0;
-                f0[i] = cur[rr * n3 + k0]; f1[i] = cur[rr * n3 + k0 + 1]; f2[i] = cur[rr * n3 + k0 + 2];
-                od[i] = cur[rr * n3 + tc];
-            }
+            for (int k = 0; k < 9; k++) { P[k] = sRow[cb][ib][k]; Pr[k] = sRow[cb][bj][k]; F[k] = sCol[cb][bi][k]; }
+            inv3_reg(P, Pi);
+            if (bi == ib) {
+                if (bj == ib) { for (int k = 0; k < 9; k++) A[k] = Pi[k]; }
+                else mul3(Pi, Pr, A);
+            } else {
+                double FP[9];
+                mul3(F, Pi, FP);
+                if (bj == ib) {
 #pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const int r = tr + 8 * i;
-                if (r < n3) {
-                    if (r >= k0 && r < k0 + 3) {
-                        nxt[r * n3 + tc] = r == k0 ? y0 : (r == k0 + 1 ? y1 : y2);
-                    } else {
-                        nxt[r * n3 + tc] = (cin ? 0.0 : od[i]) - (f0[i] * y0 + f1[i] * y1 + f2[i] * y2);
-                        if (tc == k0 && r > k0 + 2) {
-                            const double m0 = f0[i] * Pi[0] + f1[i] * Pi[3] + f2[i] * Pi[6];
-                            const double m1 = f0[i] * Pi[1] + f1[i] * Pi[4] + f2[i] * Pi[7];
-                            const double m2 = f0[i] * Pi[2] + f1[i] * Pi[5] + f2[i] * Pi[8];
-                            sNu[r] += m0 * z0 + m1 * z1 + m2 * z2;       // nu_r += (H_r K_i) ze_i
-                        }
+                    for (int k = 0; k < 9; k++) A[k] = -FP[k];
+                    if (bi > ib) {
+                        const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
+#pragma unroll
+                        for (int a = 0; a < 3; a++) sNu[3 * bi + a] += FP[a * 3] * z0 + FP[a * 3 + 1] * z1 + FP[a * 3 + 2] * z2;   // nu += (H K) ze
                     }
+                } else {
+                    double X[9];
+                    mul3(FP, Pr, X);
+#pragma unroll
+                    for (int k = 0; k < 9; k++) A[k] -= X[k];
                 }
             }
+            if (bi == ib + 1) { for (int k = 0; k < 9; k++) sRow[cb ^ 1][bj][k] = A[k]; }
+            if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[k]; }
         }
         __syncthreads();
-        double* t = cur; cur = nxt; nxt = t;
     }
-    for (int p = tid; p < n3 * n3; p += MIDT) E.d_G[p] = cur[p];
+    // G = A^-1 (block (bi, bj) from its owner), g = G nu
+    if (act) {
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) E.d_G[(size_t)(3 * bi + a) * n3 + 3 * bj + b] = A[a * 3 + b];
+        const double n0 = sNu[3 * bj], n1 = sNu[3 * bj + 1], n2 = sNu[3 * bj + 2];
+#pragma unroll
+        for (int a = 0; a < 3; a++) sPart[bi][bj][a] = A[a * 3] * n0 + A[a * 3 + 1] * n1 + A[a * 3 + 2] * n2;
+    }
+    __syncthreads();
     if (tid < n3) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        int c = 0;
-        for (; c + 3 < n3; c += 4) {
-            s0 += cur[tid * n3 + c] * sNu[c]; s1 += cur[tid * n3 + c + 1] * sNu[c + 1];
-            s2 += cur[tid * n3 + c + 2] * sNu[c + 2]; s3 += cur[tid * n3 + c + 3] * sNu[c + 3];
-        }
-        for (; c < n3; c++) s0 += cur[tid * n3 + c] * sNu[c];
-        E.d_g[tid] = (s0 + s1) + (s2 + s3);
+        const int i = tid / 3, a = tid - 3 * i;
+        double s = 0;
+        for (int j = 0; j < m; j++) s += sPart[i][j][a];
+        E.d_g[tid] = s;
     }
 }
 

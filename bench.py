@@ -144,6 +144,7 @@ def main():
         "k_threshold": cfg.rows * cfg.cols, "k_trace": cfg.rows * cfg.cols, "k_quads": cfg.rows * cfg.cols,
         "k_assemble": 84 * world_scene.M, "k_identify": cfg.rows * cfg.cols, "k_pose": 84 * world_scene.M,
         "k_ekf_plan": 16 * N, "k_ekf_gather": 8 * N * N, "k_ekf_small": 8 * N * N, "k_ekf_T": 8 * N * N, "k_ekf_update": 16 * N * N,
+        "k_ekf_mid": 8 * N * N, "k_ekf_apply": 16 * N * N,
     }
     frames_per_launch = B if not dominant.startswith("k_ekf") else 1
     launches = max(calls, 1)
