@@ -743,6 +743,7 @@ __device__ __forceinline__ void mul3(const double* X, const double* Y, double* Z
 __global__ __launch_bounds__(576) void k_ekf_mid(EkfState E) {
     __shared__ double sRow[2][kFastM][9];             // pivot row blocks (ib, bj) of the current / next step
     __shared__ double sCol[2][kFastM][9];             // pivot column blocks (bi, ib)
+    __shared__ double sY[kFastM][9];                  // S_ib^-1 * pivot row blocks of the current step
     __shared__ double sZe[kFastN3], sNu[kFastN3];
     __shared__ double sPart[kFastM][kFastM][3];
     const int tid = threadIdx.x;
@@ -827,31 +828,43 @@ __global__ __launch_bounds__(576) void k_ekf_mid(EkfState E) {
     // F S_ib^-1 of a later row block IS H_bi K_ib (the reference's own recursion, aruco_slam.cpp:146,204)
     for (int ib = 0; ib < m; ib++) {
         const int cb = ib & 1;
-        if (act) {
-            double P[9], Pi[9], Pr[9], F[9];
+        // phase 1: the pivot row (m threads): Y_bj = S_ib^-1 * A(ib, bj)  (S_ib^-1 itself at bj == ib) -> their new blocks
+        if (act && bi == ib) {
+            double P[9], Pi[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) { P[k] = sRow[cb][ib][k]; Pr[k] = sRow[cb][bj][k]; F[k] = sCol[cb][bi][k]; }
+            for (int k = 0; k < 9; k++) P[k] = sRow[cb][ib][k];
             inv3_reg(P, Pi);
-            if (bi == ib) {
-                if (bj == ib) { for (int k = 0; k < 9; k++) A[k] = Pi[k]; }
-                else mul3(Pi, Pr, A);
+            if (bj == ib) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) A[k] = Pi[k];
             } else {
-                double FP[9];
-                mul3(F, Pi, FP);
-                if (bj == ib) {
+                double Y[9];
+                mul3(Pi, A, Y);
 #pragma unroll
-                    for (int k = 0; k < 9; k++) A[k] = -FP[k];
-                    if (bi > ib) {
-                        const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
+                for (int k = 0; k < 9; k++) A[k] = Y[k];
+            }
 #pragma unroll
-                        for (int a = 0; a < 3; a++) sNu[3 * bi + a] += FP[a * 3] * z0 + FP[a * 3 + 1] * z1 + FP[a * 3 + 2] * z2;   // nu += (H K) ze
-                    }
-                } else {
-                    double X[9];
-                    mul3(FP, Pr, X);
+            for (int k = 0; k < 9; k++) sY[bj][k] = A[k];
+            if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[k]; }     // next step's F of this row
+        }
+        __syncthreads();
+        // phase 2: every other block: A(bi, bj) -= F * Y_bj with F = A(bi, ib) before this step (0 - F * S^-1 at bj == ib)
+        if (act && bi != ib) {
+            double F[9], Y[9], X[9];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) A[k] -= X[k];
+            for (int k = 0; k < 9; k++) { F[k] = sCol[cb][bi][k]; Y[k] = sY[bj][k]; }
+            mul3(F, Y, X);
+            if (bj == ib) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) A[k] = -X[k];
+                if (bi > ib) {
+                    const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
+#pragma unroll
+                    for (int a = 0; a < 3; a++) sNu[3 * bi + a] += X[a * 3] * z0 + X[a * 3 + 1] * z1 + X[a * 3 + 2] * z2;   // nu += (H K) ze
                 }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; k++) A[k] -= X[k];
             }
             if (bi == ib + 1) { for (int k = 0; k < 9; k++) sRow[cb ^ 1][bj][k] = A[k]; }
             if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[k]; }
@@ -880,7 +893,7 @@ __global__ __launch_bounds__(576) void k_ekf_mid(EkfState E) {
 constexpr int APK = kFastN3;             // padded depth of the LDS images (72)
 
 __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
-    __shared__ double sG[APK * APK];          // G, row stride APK, zero padded
+    __shared__ double sGt[APK * APK];         // G transposed: sGt[p][q], row stride APK, zero padded
     __shared__ double sVW[APK][64];           // V tile, later the W^T tile
     __shared__ double sT[APK][64];            // T tile = G V tile
     __shared__ double sg[APK];
@@ -892,17 +905,18 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     if (r0 >= N || c0 >= N) return;           // uniform
     const int tid = threadIdx.x;
-    const int x = tid & 63, grp = tid >> 6;
-    const int r = r0 + x;
+    const int tx = tid & 15, ty = tid >> 4;                   // 16 x 16 threads, 4 x 4 outputs each
 
-    // Sigma tile (16 columns per thread) fetched first; it is only needed at the very end
+    // Sigma tile fetched first; it is only needed at the very end
     double sig[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int c = c0 + grp * 16 + j;
-        sig[j] = (r < N && c < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
-    }
-    // G (zero padded to APK x APK) and the V tile
+    for (int jc = 0; jc < 4; jc++)
+#pragma unroll
+        for (int jr = 0; jr < 4; jr++) {
+            const int rr = r0 + 4 * tx + jr, c = c0 + 4 * ty + jc;
+            sig[jc * 4 + jr] = (rr < N && c < N) ? E.d_sigma[(size_t)c * ld + rr] : 0.0;
+        }
+    // G transposed (sGt[p][q] = G[q][p], zero padded to APK x APK) and the V tile
     for (int i0 = 0; i0 < APK * APK; i0 += 256 * 8) {
         double t8[8];
 #pragma unroll
@@ -912,7 +926,11 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
             t8[k] = (i < APK * APK && q < n3 && pq < n3) ? E.d_G[(size_t)q * n3 + pq] : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const int i = i0 + tid + 256 * k; if (i < APK * APK) sG[i] = t8[k]; }
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + tid + 256 * k;
+            const int q = i / APK, pq = i - q * APK;
+            if (i < APK * APK) sGt[pq * APK + q] = t8[k];
+        }
     }
     for (int i0 = 0; i0 < APK * 64; i0 += 256 * 6) {
         double t6[6];
@@ -927,21 +945,23 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
     }
     if (tid < APK) sg[tid] = tid < n3 ? E.d_g[tid] : 0.0;
     __syncthreads();
-    // T tile: thread (x, grp) forms rows grp*18 .. grp*18+17 of column x
+    // T tile (72 x 64): thread (qg, xg) forms a 9 x 2 register tile: rows 9*qg .. +8, columns 2*xg, 2*xg+1
     {
+        const int xg = tid & 31, qg = tid >> 5;               // 32 x 8
         double acc[18];
 #pragma unroll
         for (int j = 0; j < 18; j++) acc[j] = 0.0;
-        for (int pq = 0; pq < n3; pq += 2) {
-            const double v0 = sVW[pq][x], v1 = sVW[pq + 1][x];      // row n3 (if n3 is odd) is zero padded
+        for (int pq = 0; pq < n3; pq++) {
+            const double v0 = sVW[pq][2 * xg], v1 = sVW[pq][2 * xg + 1];
 #pragma unroll
-            for (int j = 0; j < 18; j++) {
-                const double* gq = &sG[(grp * 18 + j) * APK + pq];
-                acc[j] += gq[0] * v0 + gq[1] * v1;
+            for (int j = 0; j < 9; j++) {
+                const double gq = sGt[pq * APK + 9 * qg + j];
+                acc[2 * j] += gq * v0;
+                acc[2 * j + 1] += gq * v1;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 18; j++) sT[grp * 18 + j][x] = acc[j];
+        for (int j = 0; j < 9; j++) { sT[9 * qg + j][2 * xg] = acc[2 * j]; sT[9 * qg + j][2 * xg + 1] = acc[2 * j + 1]; }
     }
     __syncthreads();
     // W^T tile replaces the V tile
@@ -957,25 +977,32 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
         for (int k = 0; k < 6; k++) { const int i = i0 + tid + 256 * k; sVW[i >> 6][i & 63] = t6[k]; }
     }
     __syncthreads();
+    // Sigma tile -= W_tile^T T_tile : thread (tx, ty) owns rows 4*tx .. +3, columns 4*ty .. +3
     double acc[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.0;
     for (int pq = 0; pq < n3; pq++) {
-        const double w = sVW[pq][x];
+        double w[4], t[4];
 #pragma unroll
-        for (int j = 0; j < 16; j++) acc[j] += w * sT[pq][grp * 16 + j];
+        for (int k = 0; k < 4; k++) { w[k] = sVW[pq][4 * tx + k]; t[k] = sT[pq][4 * ty + k]; }
+#pragma unroll
+        for (int jc = 0; jc < 4; jc++)
+#pragma unroll
+            for (int jr = 0; jr < 4; jr++) acc[jc * 4 + jr] += w[jr] * t[jc];
     }
-    if (r < N) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int c = c0 + grp * 16 + j;
-            if (c < N) E.d_sigma[(size_t)c * ld + r] = sig[j] - acc[j];
+    for (int jc = 0; jc < 4; jc++) {
+        const int c = c0 + 4 * ty + jc;
+#pragma unroll
+        for (int jr = 0; jr < 4; jr++) {
+            const int rr = r0 + 4 * tx + jr;
+            if (rr < N && c < N) E.d_sigma[(size_t)c * ld + rr] = sig[jc * 4 + jr] - acc[jc * 4 + jr];
         }
-        if (blockIdx.y == 0 && grp == 0) {
-            double s0 = 0, s1 = 0;
-            for (int pq = 0; pq < n3; pq += 2) { s0 += sVW[pq][x] * sg[pq]; s1 += sVW[pq + 1][x] * sg[pq + 1]; }
-            E.d_mu[r] += s0 + s1;                                  // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
-        }
+    }
+    if (blockIdx.y == 0 && tid < 64 && r0 + tid < N) {
+        double s0 = 0, s1 = 0;
+        for (int pq = 0; pq < n3; pq += 2) { s0 += sVW[pq][tid] * sg[pq]; s1 += sVW[pq + 1][tid] * sg[pq + 1]; }
+        E.d_mu[r0 + tid] += s0 + s1;                              // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
     }
 }
 
