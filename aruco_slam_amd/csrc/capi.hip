@@ -221,7 +221,7 @@ int run_detect(aslam_ctx* c, int first, int count) {
                          alias_gray ? nullptr : c->d_gray + (size_t)f0 * frame_px, nbr, g, starts, c->d_nstarts + f0, c->d_ctr);
         prof_end(c);
         prof_begin(c, P_TRACE, st);
-        launch_prefix(st, nf, c->d_nstarts + f0, g.cap_starts, 64u, c->d_pre_trace);
+        launch_prefix(st, nf, c->d_nstarts + f0, g.cap_starts, 1u, c->d_pre_trace);
         launch_trace(st, c->nwaves, nbr, g, nf, starts, c->d_nstarts + f0, c->d_pre_trace, c->d_ctr, contours, c->d_ncontours + f0,
                      points, c->d_npoints + f0);
         prof_end(c);

@@ -264,6 +264,9 @@ __device__ __forceinline__ void walk_step(Walk& w, unsigned m) {
     w.s = (s2 + 4) & 7;
 }
 
+// Work-queue kernel.  Every lane is a small state machine (idle -> validate walk -> write walk -> idle); idle lanes are
+// refilled from the queue every iteration with ONE atomic per wave, so a wave never waits for its longest walk.
+// Tickets number the start candidates of the whole call; `pre` holds the per-frame prefix of their counts.
 __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, DetectCfg cfg, int nframes,
                                               const unsigned* __restrict__ starts, const unsigned* __restrict__ n_starts,
                                               const unsigned* __restrict__ pre, Counters* ctr,
@@ -275,69 +278,92 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
     __syncthreads();
     const unsigned total = sPre[nframes];
     const int pitch = cfg.pitch, cols = cfg.cols;
-    for (;;) {
-        unsigned ticket = 0;
-        if (lane == 0) ticket = atomicAdd(&ctr->q_trace, 1u);
-        ticket = __shfl(ticket, 0);
-        if (ticket >= total) break;
-        const int f = ticket_frame(sPre, nframes, ticket);
-        const unsigned nst = min(n_starts[f], cfg.cap_starts);
-        const unsigned idx = (ticket - sPre[f]) * 64u + lane;
-        if (idx < nst) {
-            unsigned e = starts[(size_t)f * cfg.cap_starts + idx];
-            int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
-            unsigned sc = (e >> 24) & 3u, type = (e >> 26) & 1u;
-            const uint8_t* plane = nbr + ((size_t)f * kScales + sc) * cfg.rows * pitch;
-            const int key0 = y * cols + x;
-            if (type) x -= 1;                                  // hole border starts on the pixel left of the hole
-            unsigned m0 = plane[(size_t)y * pitch + x];
-            const int s0 = type ? first_hole(m0) : first_outer(m0);
-            const int sx = x, sy = y;
 
-            Walk w{sx, sy, s0};
-            long long area = 0;
-            int n = 0;
-            bool alive = true;
-            for (;;) {
-                unsigned m = plane[(size_t)w.y * pitch + w.x];
-                // is this state the start state of another scan candidate of my type with a smaller key?
-                if (type == 0) {
-                    if ((m & 0x1Eu) == 0 && w.s == first_outer(m) && w.y * cols + w.x < key0) { alive = false; break; }
-                } else {
-                    if ((m & 3u) == 2u && w.s == first_hole(m) && w.y * cols + w.x + 1 < key0) { alive = false; break; }
+    int mode = 0;                       // 0 idle, 1 validate, 2 write
+    bool drained = false;               // the queue is empty (wave-uniform)
+    const uint8_t* plane = nbr;
+    Walk w{0, 0, 0};
+    int sx = 0, sy = 0, s0 = 0, key0 = 0, n = 0, wi = 0, f = 0;
+    unsigned type = 0, sc = 0;
+    long long area = 0;
+    unsigned* dst = points;
+
+    for (;;) {
+        // ---- refill idle lanes ----
+        const unsigned long long idle = __ballot(mode == 0);
+        if (idle != 0ull && !drained) {
+            const int cnt = __popcll(idle);
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&ctr->q_trace, (unsigned)cnt);
+            base = __shfl(base, 0);
+            if (base + (unsigned)cnt >= total) drained = true;
+            if (mode == 0) {
+                const unsigned ticket = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+                if (ticket < total) {
+                    f = ticket_frame(sPre, nframes, ticket);
+                    const unsigned e = starts[(size_t)f * cfg.cap_starts + (ticket - sPre[f])];
+                    int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
+                    sc = (e >> 24) & 3u;
+                    type = (e >> 26) & 1u;
+                    plane = nbr + ((size_t)f * kScales + sc) * cfg.rows * pitch;
+                    key0 = y * cols + x;
+                    if (type) x -= 1;                              // hole border starts on the pixel left of the hole
+                    const unsigned m0 = plane[(size_t)y * pitch + x];
+                    s0 = type ? first_hole(m0) : first_outer(m0);
+                    sx = x; sy = y;
+                    w = Walk{sx, sy, s0};
+                    area = 0;
+                    n = 0;
+                    mode = 1;
                 }
-                int px = w.x, py = w.y;
+            }
+        }
+        if (__ballot(mode != 0) == 0ull) break;
+
+        // ---- one step per busy lane ----
+        if (mode == 1) {
+            const unsigned m = plane[(size_t)w.y * pitch + w.x];
+            bool dead = false;
+            // is this state the start state of another scan candidate of my type with a smaller key?
+            if (type == 0) dead = (m & 0x1Eu) == 0 && w.s == first_outer(m) && w.y * cols + w.x < key0;
+            else dead = (m & 3u) == 2u && w.s == first_hole(m) && w.y * cols + w.x + 1 < key0;
+            if (dead) {
+                mode = 0;
+            } else {
+                const int px = w.x, py = w.y;
                 walk_step(w, m);
                 area += (long long)px * w.y - (long long)w.x * py;
                 n++;
-                if (w.x == sx && w.y == sy && w.s == s0) break;
-                if (n > cfg.max_perim) { alive = false; break; }
-            }
-            if (alive) {
-                bool is_hole = area > 0;                         // outer borders run counter-clockwise on screen
-                if ((unsigned)is_hole != type) alive = false;
-                if (n < cfg.min_perim || n > cfg.max_perim) alive = false;
-            }
-            if (alive) {
-                unsigned ci = atomicAdd(&n_contours[f], 1u);
-                unsigned off = atomicAdd(&n_points[f], (unsigned)n);
-                if (ci >= cfg.cap_contours) atomicOr(&ctr->overflow, (unsigned)kOvfContours);
-                else if ((unsigned long long)off + (unsigned)n > cfg.cap_points) {
-                    atomicOr(&ctr->overflow, (unsigned)kOvfPoints);
-                    ContourRec rec{(unsigned)f, sc, (unsigned)key0, 0u, 0u, (short)sx, (short)sy, s0};
-                    contours[(size_t)f * cfg.cap_contours + ci] = rec;
-                } else {
-                    ContourRec rec{(unsigned)f, sc, (unsigned)key0, (unsigned)n, off, (short)sx, (short)sy, s0};
-                    contours[(size_t)f * cfg.cap_contours + ci] = rec;
-                    unsigned* dst = points + (size_t)f * cfg.cap_points + off;
-                    Walk v{sx, sy, s0};
-                    for (int i = 0; i < n; i++) {
-                        dst[i] = ((unsigned)v.x & 0xFFFFu) | ((unsigned)v.y << 16);
-                        unsigned m = plane[(size_t)v.y * pitch + v.x];
-                        walk_step(v, m);
+                if (w.x == sx && w.y == sy && w.s == s0) {
+                    // closed: keep it only if this was the start the sequential scan would have used
+                    const bool is_hole = area > 0;                 // outer borders run counter-clockwise on screen
+                    bool keep = ((unsigned)is_hole == type) && n >= cfg.min_perim && n <= cfg.max_perim;
+                    mode = 0;
+                    if (keep) {
+                        const unsigned ci = atomicAdd(&n_contours[f], 1u);
+                        const unsigned off = atomicAdd(&n_points[f], (unsigned)n);
+                        if (ci >= cfg.cap_contours) {
+                            atomicOr(&ctr->overflow, (unsigned)kOvfContours);
+                        } else if ((unsigned long long)off + (unsigned)n > cfg.cap_points) {
+                            atomicOr(&ctr->overflow, (unsigned)kOvfPoints);
+                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)key0, 0u, 0u, (short)sx, (short)sy, s0};
+                        } else {
+                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)key0, (unsigned)n, off, (short)sx, (short)sy, s0};
+                            dst = points + (size_t)f * cfg.cap_points + off;
+                            w = Walk{sx, sy, s0};
+                            wi = 0;
+                            mode = 2;
+                        }
                     }
+                } else if (n > cfg.max_perim) {
+                    mode = 0;
                 }
             }
+        } else if (mode == 2) {
+            dst[wi] = ((unsigned)w.x & 0xFFFFu) | ((unsigned)w.y << 16);
+            const unsigned m = plane[(size_t)w.y * pitch + w.x];
+            walk_step(w, m);
+            if (++wi >= n) mode = 0;
         }
     }
 }
