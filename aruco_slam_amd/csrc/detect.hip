@@ -264,6 +264,8 @@ __device__ __forceinline__ void walk_step(Walk& w, unsigned m) {
     w.s = (s2 + 4) & 7;
 }
 
+constexpr int kTraceChunk = 256;
+
 // Work-queue kernel.  Every lane is a small state machine (idle -> validate walk -> write walk -> idle); idle lanes are
 // refilled from the queue every iteration with ONE atomic per wave, so a wave never waits for its longest walk.
 // Tickets number the start candidates of the whole call; `pre` holds the per-frame prefix of their counts.
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
 
     int mode = 0;                       // 0 idle, 1 validate, 2 write
     bool drained = false;               // the queue is empty (wave-uniform)
+    unsigned lo = 0, hi = 0;            // the wave's private ticket range (wave-uniform)
     const uint8_t* plane = nbr;
     Walk w{0, 0, 0};
     int sx = 0, sy = 0, s0 = 0, key0 = 0, n = 0, wi = 0, f = 0;
@@ -289,34 +292,38 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
     unsigned* dst = points;
 
     for (;;) {
-        // ---- refill idle lanes ----
+        // ---- refill idle lanes from the wave's private ticket range; a new range costs one atomic per kTraceChunk tickets ----
         const unsigned long long idle = __ballot(mode == 0);
         if (idle != 0ull && !drained) {
-            const int cnt = __popcll(idle);
-            unsigned base = 0;
-            if (lane == 0) base = atomicAdd(&ctr->q_trace, (unsigned)cnt);
-            base = __shfl(base, 0);
-            if (base + (unsigned)cnt >= total) drained = true;
-            if (mode == 0) {
-                const unsigned ticket = base + (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
-                if (ticket < total) {
-                    f = ticket_frame(sPre, nframes, ticket);
-                    const unsigned e = starts[(size_t)f * cfg.cap_starts + (ticket - sPre[f])];
-                    int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
-                    sc = (e >> 24) & 3u;
-                    type = (e >> 26) & 1u;
-                    plane = nbr + ((size_t)f * kScales + sc) * cfg.rows * pitch;
-                    key0 = y * cols + x;
-                    if (type) x -= 1;                              // hole border starts on the pixel left of the hole
-                    const unsigned m0 = plane[(size_t)y * pitch + x];
-                    s0 = type ? first_hole(m0) : first_outer(m0);
-                    sx = x; sy = y;
-                    w = Walk{sx, sy, s0};
-                    area = 0;
-                    n = 0;
-                    mode = 1;
-                }
+            if (lo == hi) {                                       // wave-uniform
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&ctr->q_trace, (unsigned)kTraceChunk);
+                base = __shfl(base, 0);
+                lo = base;
+                hi = min(base + (unsigned)kTraceChunk, total);
+                if (lo >= total) { drained = true; lo = hi = 0; }
             }
+            const unsigned take = min((unsigned)__popcll(idle), hi - lo);
+            const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+            if (mode == 0 && rank < take) {
+                const unsigned ticket = lo + rank;
+                if (!(ticket >= sPre[f] && ticket < sPre[f + 1])) f = ticket_frame(sPre, nframes, ticket);
+                const unsigned e = starts[(size_t)f * cfg.cap_starts + (ticket - sPre[f])];
+                int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
+                sc = (e >> 24) & 3u;
+                type = (e >> 26) & 1u;
+                plane = nbr + ((size_t)f * kScales + sc) * cfg.rows * pitch;
+                key0 = y * cols + x;
+                if (type) x -= 1;                                  // hole border starts on the pixel left of the hole
+                const unsigned m0 = plane[(size_t)y * pitch + x];
+                s0 = type ? first_hole(m0) : first_outer(m0);
+                sx = x; sy = y;
+                w = Walk{sx, sy, s0};
+                area = 0;
+                n = 0;
+                mode = 1;
+            }
+            lo += take;
         }
         if (__ballot(mode != 0) == 0ull) break;
 
