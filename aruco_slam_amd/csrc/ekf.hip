@@ -740,7 +740,8 @@ __device__ __forceinline__ void mul3(const double* X, const double* Y, double* Z
         for (int j = 0; j < 3; j++) Z[i * 3 + j] = X[i * 3] * Y[j] + X[i * 3 + 1] * Y[3 + j] + X[i * 3 + 2] * Y[6 + j];
 }
 
-__global__ __launch_bounds__(576) void k_ekf_mid(EkfState E) {
+// <= 128 VGPRs (4 waves per SIMD) so that the workgroup always finds room beside the persistent detection waves of the other stream
+__global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
     __shared__ double sRow[2][kFastM][9];             // pivot row blocks (ib, bj) of the current / next step
     __shared__ double sCol[2][kFastM][9];             // pivot column blocks (bi, ib)
     __shared__ double sY[kFastM][9];                  // S_ib^-1 * pivot row blocks of the current step
