@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=78, help="frames per step")
+    ap.add_argument("--batch", type=int, default=200, help="frames per step (<= half a lap keeps consecutive steps on disjoint slots)")
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--cpu-sample", type=int, default=195, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-ekf", action="store_true", help="detect + pose only (BASELINE config 5 style)")
