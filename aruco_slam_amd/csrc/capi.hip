@@ -211,7 +211,7 @@ int run_detect(aslam_ctx* c, int first, int count) {
         HIP_TRY(c, hipMemsetAsync(c->d_npoints + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_ncand + f0, 0, sizeof(unsigned) * nf, st));
         const uint8_t* in = c->d_in + (size_t)f0 * c->in_frame_bytes;
-        uint8_t* nbr = c->d_nbr + (size_t)f0 * kScales * g.rows * g.pitch;
+        uint8_t* nbr = c->d_nbr + (size_t)f0 * kScales * nbr_plane_bytes(g.rows, g.pitch);
         const uint8_t* gray = alias_gray ? in : c->d_gray + (size_t)f0 * frame_px;
         unsigned* starts = c->d_starts + (size_t)f0 * g.cap_starts;
         ContourRec* contours = c->d_contours + (size_t)f0 * g.cap_contours;
@@ -354,7 +354,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && hipEventCreateWithFlags(&c->ev_ekf, hipEventDisableTiming) == hipSuccess;
     ok = ok && dalloc(&c->d_in, px * 3 * B) == hipSuccess;
     ok = ok && dalloc(&c->d_gray, px * B) == hipSuccess;
-    ok = ok && dalloc(&c->d_nbr, (size_t)kScales * init->max_rows * pitch * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_nbr, (size_t)kScales * nbr_plane_bytes(init->max_rows, (int)pitch) * B) == hipSuccess;
     ok = ok && dalloc(&c->d_starts, (size_t)c->init.cap_starts_per_frame * B) == hipSuccess;
     ok = ok && dalloc(&c->d_nstarts, B) == hipSuccess;
     ok = ok && dalloc(&c->d_ctr, 1) == hipSuccess;
@@ -673,9 +673,11 @@ int aslam_debug_get_nbr(aslam_ctx* c, int slot, int scale, uint8_t* out) {
     if (r) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const DetectCfg& g = c->cfg;
-    const uint8_t* src = c->d_nbr + (((size_t)slot * kScales + scale) * g.rows) * g.pitch;
-    HIP_TRY(c, hipMemcpy2DAsync(out, g.cols, src, g.pitch, g.cols, g.rows, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t pb = nbr_plane_bytes(g.rows, g.pitch);
+    std::vector<uint8_t> tiled(pb);
+    HIP_TRY(c, hipMemcpy(tiled.data(), c->d_nbr + ((size_t)slot * kScales + scale) * pb, pb, hipMemcpyDeviceToHost));
+    for (int y = 0; y < g.rows; y++)
+        for (int x = 0; x < g.cols; x++) out[(size_t)y * g.cols + x] = tiled[nbr_index(x, y, g.pitch)];     // un-tile for the caller
     return ASLAM_OK;
 }
 

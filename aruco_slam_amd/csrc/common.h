@@ -92,6 +92,13 @@ struct SlamParams {
     int pad;
 };
 
+// Neighbour-mask planes are stored in 8x8-pixel tiles (one 64-byte line per tile) so that a border walk, which moves one
+// pixel at a time in any direction, stays on the same cache line for several steps.  pitch is a multiple of 64.
+__host__ __device__ inline size_t nbr_index(int x, int y, int pitch) {
+    return ((size_t)(y >> 3) * (size_t)(pitch >> 3) + (size_t)(x >> 3)) * 64u + (size_t)((y & 7) << 3) + (size_t)(x & 7);
+}
+__host__ __device__ inline size_t nbr_plane_bytes(int rows, int pitch) { return (size_t)((rows + 7) & ~7) * (size_t)pitch; }
+
 // start-list entry: x[0:12) y[12:24) scale[24:26) type[26] frame[32:48)
 __host__ __device__ inline unsigned long long pack_start(unsigned x, unsigned y, unsigned scale, unsigned type, unsigned frame) {
     return (unsigned long long)x | ((unsigned long long)y << 12) | ((unsigned long long)scale << 24) |

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         if (gy < rows) {
 #pragma unroll
             for (int s = 0; s < kScales; s++) {
-                unsigned* dst = reinterpret_cast<unsigned*>(nbr + (((size_t)b * kScales + s) * rows + gy) * cfg.pitch + x0 + tx4);
+                unsigned* dst = reinterpret_cast<unsigned*>(nbr + ((size_t)b * kScales + s) * nbr_plane_bytes(rows, cfg.pitch) +
+                                                            nbr_index(x0 + tx4, gy, cfg.pitch));
                 *dst = out[s];
             }
         }
@@ -312,10 +313,10 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                 int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
                 sc = (e >> 24) & 3u;
                 type = (e >> 26) & 1u;
-                plane = nbr + ((size_t)f * kScales + sc) * cfg.rows * pitch;
+                plane = nbr + ((size_t)f * kScales + sc) * nbr_plane_bytes(cfg.rows, pitch);
                 key0 = y * cols + x;
                 if (type) x -= 1;                                  // hole border starts on the pixel left of the hole
-                const unsigned m0 = plane[(size_t)y * pitch + x];
+                const unsigned m0 = plane[nbr_index(x, y, pitch)];
                 s0 = type ? first_hole(m0) : first_outer(m0);
                 sx = x; sy = y;
                 w = Walk{sx, sy, s0};
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
 
         // ---- one step per busy lane ----
         if (mode == 1) {
-            const unsigned m = plane[(size_t)w.y * pitch + w.x];
+            const unsigned m = plane[nbr_index(w.x, w.y, pitch)];
             bool dead = false;
             // is this state the start state of another scan candidate of my type with a smaller key?
             if (type == 0) dead = (m & 0x1Eu) == 0 && w.s == first_outer(m) && w.y * cols + w.x < key0;
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
             }
         } else if (mode == 2) {
             dst[wi] = ((unsigned)w.x & 0xFFFFu) | ((unsigned)w.y << 16);
-            const unsigned m = plane[(size_t)w.y * pitch + w.x];
+            const unsigned m = plane[nbr_index(w.x, w.y, pitch)];
             walk_step(w, m);
             if (++wi >= n) mode = 0;
         }
