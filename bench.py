@@ -151,8 +151,19 @@ def main():
     avg_s = total_ms / 1e3 / launches
     alg_bytes = per_frame_bytes[dominant] * (args.steps * B / launches if not dominant.startswith("k_ekf") else 1)
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+    # HBM traffic of that kernel per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+    # runs of this same command; profiles/r01_pmc_traffic.json).  FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
+    # (MI355X_MICROARCH.md §HBM); the figure is given uncorrected, scaled to this run's frames per launch.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dominant)
+        if pmc:
+            scale = 1.0 if dominant.startswith("k_ekf") else (args.steps * B / launches) / 200.0
+            traffic = int((pmc.get("FETCH_SIZE_KB_per_launch", 0) + pmc.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 * scale)
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 6), "traffic": None, "avg_launch_us": round(avg_s * 1e6, 2),
+                "frac": round(achieved / 8000.0, 6), "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2),
                 "alg_bytes_per_launch": int(alg_bytes),
                 "kernel_ms_per_step": {k: round(v[1] / max(args.steps, 1), 4) for k, v in prof2.items()}}
 
