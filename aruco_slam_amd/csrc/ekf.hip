@@ -48,9 +48,11 @@ __device__ void inv3_pp(const double* A, double* out) {   // 3x3 inverse by part
 }
 
 // ---- predict (aruco_slam.cpp:35-73), executed by one workgroup -------------------------------------------
-// Sigma <- Hx Sigma Hx^T + F Qk F^T with Hx = identity except its 3x3 corner: rows 0..2 first, then columns 0..2.
+// Sigma <- Hx Sigma Hx^T + F Qk F^T with Hx = identity except its 3x3 corner.  Rows 0..2 are multiplied by H from the left,
+// columns 0..2 by H^T from the right; outside the 3x3 corner the two touch disjoint entries, so one pass does both
+// (thread t >= 3: entries (0..2, t) and (t, 0..2); thread 0: the corner (H S3) H^T + Qk).  sMu receives the new pose.
 __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int N,
-                              double* sH /*shared 9*/, double* sQ /*shared 9*/) {
+                              double* sH /*shared 9*/, double* sQ /*shared 9*/, double* sMu /*shared 3*/) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int ld = E.ld;
     if (tid == 0) {
@@ -59,13 +61,13 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
         double l_ = 2 * sp.b;
         double delta_theta = (delta_sr - delta_sl) / l_;
         double delta_s = 0.5 * (delta_sr + delta_sl);
-        double tmp_th = E.d_mu[2] + 0.5 * delta_theta;
+        const double m0 = E.d_mu[0], m1 = E.d_mu[1], m2 = E.d_mu[2];
+        double tmp_th = m2 + 0.5 * delta_theta;
         double c = cos(tmp_th), s = sin(tmp_th);
-        E.d_mu[0] += delta_s * c;
-        E.d_mu[1] += delta_s * s;
-        double th = E.d_mu[2] + delta_theta;
+        double th = m2 + delta_theta;
         wrap1(th);
-        E.d_mu[2] = th;
+        sMu[0] = m0 + delta_s * c; sMu[1] = m1 + delta_s * s; sMu[2] = th;
+        E.d_mu[0] = sMu[0]; E.d_mu[1] = sMu[1]; E.d_mu[2] = sMu[2];
         sH[0] = 1.0; sH[1] = 0.0; sH[2] = -delta_s * s;
         sH[3] = 0.0; sH[4] = 1.0; sH[5] = delta_s * c;
         sH[6] = 0.0; sH[7] = 0.0; sH[8] = 1.0;
@@ -76,39 +78,39 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
             for (int j = 0; j < 3; j++) sQ[i * 3 + j] = wkh[i * 2] * su0 * wkh[j * 2] + wkh[i * 2 + 1] * su1 * wkh[j * 2 + 1];
     }
     __syncthreads();
-    for (int j = tid; j < N; j += nt) {
-        double* col = E.d_sigma + (size_t)j * ld;
-        double a = col[0], b = col[1], c = col[2];
+    for (int t = 3 + tid; t < N; t += nt) {
+        double* col = E.d_sigma + (size_t)t * ld;
+        const double a = col[0], b = col[1], c = col[2];
+        const double ra = E.d_sigma[t], rb = E.d_sigma[(size_t)ld + t], rc = E.d_sigma[(size_t)2 * ld + t];
         col[0] = sH[0] * a + sH[1] * b + sH[2] * c;
         col[1] = sH[3] * a + sH[4] * b + sH[5] * c;
         col[2] = sH[6] * a + sH[7] * b + sH[8] * c;
+        E.d_sigma[t] = ra * sH[0] + rb * sH[1] + rc * sH[2];
+        E.d_sigma[(size_t)ld + t] = ra * sH[3] + rb * sH[4] + rc * sH[5];
+        E.d_sigma[(size_t)2 * ld + t] = ra * sH[6] + rb * sH[7] + rc * sH[8];
     }
-    __syncthreads();
-    for (int i = tid; i < N; i += nt) {
-        double a = E.d_sigma[i], b = E.d_sigma[(size_t)ld + i], c = E.d_sigma[(size_t)2 * ld + i];
-        E.d_sigma[i] = a * sH[0] + b * sH[1] + c * sH[2];
-        E.d_sigma[(size_t)ld + i] = a * sH[3] + b * sH[4] + c * sH[5];
-        E.d_sigma[(size_t)2 * ld + i] = a * sH[6] + b * sH[7] + c * sH[8];
-    }
-    __syncthreads();
-    if (tid < 9) {
-        int i = tid / 3, j = tid - 3 * i;
-        E.d_sigma[(size_t)j * ld + i] += sQ[i * 3 + j];
+    if (tid == 0) {
+        double S[9], T[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) S[i * 3 + j] = E.d_sigma[(size_t)j * ld + i];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[i * 3 + j] = sH[i * 3] * S[j] + sH[i * 3 + 1] * S[3 + j] + sH[i * 3 + 2] * S[6 + j];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                E.d_sigma[(size_t)j * ld + i] = (T[i * 3] * sH[j * 3] + T[i * 3 + 1] * sH[j * 3 + 1] + T[i * 3 + 2] * sH[j * 3 + 2]) + sQ[i * 3 + j];
     }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void k_ekf_predict(EkfState E, SlamParams sp, double wl, double wr, double dt) {
-    __shared__ double sH[9], sQ[9];
+    __shared__ double sH[9], sQ[9], sMu[3];
     const int N = 3 + 3 * (*E.d_L);
-    predict_block(E, sp, wl, wr, dt, N, sH, sQ);
+    predict_block(E, sp, wl, wr, dt, N, sH, sQ, sMu);
 }
 
 // ---- plan: predict + queue order + augment + update plan (one workgroup) -----------------------------------
 __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, double wl, double wr, double dt, int do_predict,
                                                   const ObsRaw* __restrict__ obs, const unsigned* __restrict__ n_markers,
                                                   Counters* ctr, int max_m) {
-    __shared__ double sH[9], sQ[9];
+    __shared__ double sH[9], sQ[9], sMu[3];
     __shared__ ObsRaw sObs[kMarkerMax];
     __shared__ LastObs sLast[kMarkerMax];
     __shared__ int sHeap[kMarkerMax];          // heap of observation slots
@@ -122,19 +124,26 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     const int tid = threadIdx.x, nt = blockDim.x;
     const int ld = E.ld;
 
+    // every independent global load is issued before the first dependent one: counts, this thread's observation and
+    // previous-frame entry, the old pose
     const int L0 = *E.d_L;
-    if (do_predict) predict_block(E, sp, wl, wr, dt, 3 + 3 * L0, sH, sQ);
-
     const int nM = (int)min(*n_markers, (unsigned)kMarkerMax);
-    const double mu0x = E.d_mu[0], mu0y = E.d_mu[1], mu0t = E.d_mu[2];     // frozen pre-frame robot pose (Q1)
-
-    for (int i = tid; i < nM; i += nt) {
-        ObsRaw o = obs[i];
-        sObs[i] = o;
-        int index = -2;
-        if (o.valid) index = (o.id >= 0 && o.id < kIdTableSize) ? E.d_id2idx[o.id] : -1;   // checkLandmark (aruco_slam.cpp:423-435)
-        sIndex[i] = index;
+    const int nl = min(*E.d_nlast, kMarkerMax);
+    ObsRaw myObs;
+    LastObs myLast;
+    if (tid < kMarkerMax) { myObs = obs[tid]; myLast = E.d_last[tid]; }          // slots beyond nM / nl are never used
+    double mu0x = E.d_mu[0], mu0y = E.d_mu[1], mu0t = E.d_mu[2];
+    if (do_predict) {
+        predict_block(E, sp, wl, wr, dt, 3 + 3 * L0, sH, sQ, sMu);
+        mu0x = sMu[0]; mu0y = sMu[1]; mu0t = sMu[2];                             // frozen pre-frame robot pose (Q1)
     }
+    if (tid < nM) {
+        sObs[tid] = myObs;
+        int index = -2;
+        if (myObs.valid) index = (myObs.id >= 0 && myObs.id < kIdTableSize) ? E.d_id2idx[myObs.id] : -1;   // checkLandmark (aruco_slam.cpp:423-435)
+        sIndex[tid] = index;
+    }
+    if (tid < nl) sLast[tid] = myLast;
     if (tid == 0) { sNNew = 0; sNPop = 0; sDup = 0; }
     __syncthreads();
     for (int i = tid; i < nM; i += nt) {
@@ -278,9 +287,6 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     }
 
     // ---- already mapped (aruco_slam.cpp:108-207): every record is independent of the others (frozen mean, Q1) ----
-    const int nl = min(*E.d_nlast, kMarkerMax);
-    for (int k = tid; k < nl; k += nt) sLast[k] = E.d_last[k];
-    __syncthreads();
     for (int q = nnew + tid; q < np; q += nt) {
         const ObsRaw o = sObs[sOrder[q]];
         // "stationary" test against the previous frame (aruco_slam.cpp:192-198): a no-op branch (quirk Q2)
@@ -908,7 +914,8 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;                   // 16 x 16 threads, 4 x 4 outputs each
 
-    // Sigma tile fetched first; it is only needed at the very end
+    // Every global load of the workgroup is issued up front (Sigma tile, G, V tile, W^T tile: ~75 loads per thread in
+    // flight) so the kernel pays the dependent-launch memory latency once, not once per staging loop.
     double sig[16];
 #pragma unroll
     for (int jc = 0; jc < 4; jc++)
@@ -917,34 +924,33 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
             const int rr = r0 + 4 * tx + jr, c = c0 + 4 * ty + jc;
             sig[jc * 4 + jr] = (rr < N && c < N) ? E.d_sigma[(size_t)c * ld + rr] : 0.0;
         }
-    // G transposed (sGt[p][q] = G[q][p], zero padded to APK x APK) and the V tile
-    for (int i0 = 0; i0 < APK * APK; i0 += 256 * 8) {
-        double t8[8];
+    constexpr int NG = (APK * APK + 255) / 256;      // 21
+    constexpr int NV = APK * 64 / 256;               // 18
+    double tg[NG], tv[NV], tw[NV];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = i0 + tid + 256 * k;
-            const int q = i / APK, pq = i - q * APK;
-            t8[k] = (i < APK * APK && q < n3 && pq < n3) ? E.d_G[(size_t)q * n3 + pq] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = i0 + tid + 256 * k;
-            const int q = i / APK, pq = i - q * APK;
-            if (i < APK * APK) sGt[pq * APK + q] = t8[k];
-        }
+    for (int k = 0; k < NG; k++) {
+        const int i = tid + 256 * k;
+        const int q = i / APK, pq = i - q * APK;
+        tg[k] = (i < APK * APK && q < n3 && pq < n3) ? E.d_G[(size_t)q * n3 + pq] : 0.0;
     }
-    for (int i0 = 0; i0 < APK * 64; i0 += 256 * 6) {
-        double t6[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int i = i0 + tid + 256 * k;
-            const int pq = i >> 6, xx = i & 63;
-            t6[k] = (pq < n3 && c0 + xx < N) ? E.d_V[(size_t)pq * ld + c0 + xx] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) { const int i = i0 + tid + 256 * k; sVW[i >> 6][i & 63] = t6[k]; }
+    for (int k = 0; k < NV; k++) {
+        const int i = tid + 256 * k;
+        const int pq = i >> 6, xx = i & 63;
+        tv[k] = (pq < n3 && c0 + xx < N) ? E.d_V[(size_t)pq * ld + c0 + xx] : 0.0;
+        tw[k] = (pq < n3 && r0 + xx < N) ? E.d_Wt[(size_t)pq * ld + r0 + xx] : 0.0;
     }
-    if (tid < APK) sg[tid] = tid < n3 ? E.d_g[tid] : 0.0;
+    const double gval = (tid < APK && tid < n3) ? E.d_g[tid] : 0.0;
+    // G transposed into LDS (sGt[p][q] = G[q][p], zero padded to APK x APK) and the V tile
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+        const int i = tid + 256 * k;
+        const int q = i / APK, pq = i - q * APK;
+        if (i < APK * APK) sGt[pq * APK + q] = tg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) { const int i = tid + 256 * k; sVW[i >> 6][i & 63] = tv[k]; }
+    if (tid < APK) sg[tid] = gval;
     __syncthreads();
     // T tile (72 x 64): thread (qg, xg) forms a 9 x 2 register tile: rows 9*qg .. +8, columns 2*xg, 2*xg+1
     {
@@ -965,18 +971,9 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
         for (int j = 0; j < 9; j++) { sT[9 * qg + j][2 * xg] = acc[2 * j]; sT[9 * qg + j][2 * xg + 1] = acc[2 * j + 1]; }
     }
     __syncthreads();
-    // W^T tile replaces the V tile
-    for (int i0 = 0; i0 < APK * 64; i0 += 256 * 6) {
-        double t6[6];
+    // W^T tile (already in registers) replaces the V tile
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int i = i0 + tid + 256 * k;
-            const int pq = i >> 6, xx = i & 63;
-            t6[k] = (pq < n3 && r0 + xx < N) ? E.d_Wt[(size_t)pq * ld + r0 + xx] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) { const int i = i0 + tid + 256 * k; sVW[i >> 6][i & 63] = t6[k]; }
-    }
+    for (int k = 0; k < NV; k++) { const int i = tid + 256 * k; sVW[i >> 6][i & 63] = tw[k]; }
     __syncthreads();
     // Sigma tile -= W_tile^T T_tile : thread (tx, ty) owns rows 4*tx .. +3, columns 4*ty .. +3
     double acc[16];
