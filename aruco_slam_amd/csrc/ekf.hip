@@ -748,9 +748,9 @@ __device__ __forceinline__ void mul3(const double* X, const double* Y, double* Z
 
 // <= 128 VGPRs (4 waves per SIMD) so that the workgroup always finds room beside the persistent detection waves of the other stream
 __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
-    __shared__ double sRow[2][kFastM][9];             // pivot row blocks (ib, bj) of the current / next step
     __shared__ double sCol[2][kFastM][9];             // pivot column blocks (bi, ib)
     __shared__ double sY[kFastM][9];                  // S_ib^-1 * pivot row blocks of the current step
+    __shared__ double sPinv[9];                       // S_ib^-1 of the current step (formed at the end of the previous one)
     __shared__ double sZe[kFastN3], sNu[kFastN3];
     __shared__ double sPart[kFastM][kFastM][3];
     const int tid = threadIdx.x;
@@ -827,8 +827,12 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
                 A[a * 3 + b] = s;
             }
         if (bi == bj) { A[0] += ui.r[0]; A[4] += ui.r[1]; A[8] += ui.r[2]; }
-        if (bi == 0) { for (int k = 0; k < 9; k++) sRow[0][bj][k] = A[k]; }
         if (bj == 0) { for (int k = 0; k < 9; k++) sCol[0][bi][k] = A[k]; }
+        if (bi == 0 && bj == 0) {
+            double Pn[9];
+            inv3_reg(A, Pn);
+            for (int k = 0; k < 9; k++) sPinv[k] = Pn[k];
+        }
     }
     __syncthreads();
     // block Gauss-Jordan with 3x3 pivots: pivot block ib IS S_ib = H_ib Sigma_{ib-1} H_ib^T + R_ib, and the block multiplier
@@ -837,10 +841,9 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
         const int cb = ib & 1;
         // phase 1: the pivot row (m threads): Y_bj = S_ib^-1 * A(ib, bj)  (S_ib^-1 itself at bj == ib) -> their new blocks
         if (act && bi == ib) {
-            double P[9], Pi[9];
+            double Pi[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) P[k] = sRow[cb][ib][k];
-            inv3_reg(P, Pi);
+            for (int k = 0; k < 9; k++) Pi[k] = sPinv[k];
             if (bj == ib) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) A[k] = Pi[k];
@@ -873,8 +876,13 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) A[k] -= X[k];
             }
-            if (bi == ib + 1) { for (int k = 0; k < 9; k++) sRow[cb ^ 1][bj][k] = A[k]; }
             if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[k]; }
+            if (bi == ib + 1 && bj == ib + 1) {                  // next pivot block S_{ib+1}: invert it now
+                double Pn[9];
+                inv3_reg(A, Pn);
+#pragma unroll
+                for (int k = 0; k < 9; k++) sPinv[k] = Pn[k];
+            }
         }
         __syncthreads();
     }
@@ -958,6 +966,7 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
         double acc[18];
 #pragma unroll
         for (int j = 0; j < 18; j++) acc[j] = 0.0;
+#pragma unroll 4
         for (int pq = 0; pq < n3; pq++) {
             const double v0 = sVW[pq][2 * xg], v1 = sVW[pq][2 * xg + 1];
 #pragma unroll
@@ -979,6 +988,7 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
     double acc[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.0;
+#pragma unroll 4
     for (int pq = 0; pq < n3; pq++) {
         double w[4], t[4];
 #pragma unroll
