@@ -966,7 +966,6 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
         double acc[18];
 #pragma unroll
         for (int j = 0; j < 18; j++) acc[j] = 0.0;
-#pragma unroll 4
         for (int pq = 0; pq < n3; pq++) {
             const double v0 = sVW[pq][2 * xg], v1 = sVW[pq][2 * xg + 1];
 #pragma unroll
@@ -988,7 +987,6 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
     double acc[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) acc[j] = 0.0;
-#pragma unroll 4
     for (int pq = 0; pq < n3; pq++) {
         double w[4], t[4];
 #pragma unroll

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--cpu-sample", type=int, default=195, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-ekf", action="store_true", help="detect + pose only (BASELINE config 5 style)")
+    ap.add_argument("--waves", type=int, default=0, help="wavefronts of the work-queue kernels (0 = library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -54,7 +55,8 @@ def main():
     lap = world_scene.lap_length()
     B = min(args.batch, lap)
     ctx = capi.Context(device_id=local_rank, max_rows=cfg.rows, max_cols=cfg.cols, max_batch=lap,
-                       max_landmarks=world_scene.L + 8)
+                       max_landmarks=world_scene.L + 8, persistent_waves=args.waves,
+                       max_updates_per_frame=24 if world_scene.M <= 24 else 64)
     D = np.zeros(5)
     ctx.set_camera(world_scene.K, D)
 
