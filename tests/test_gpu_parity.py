@@ -153,3 +153,33 @@ def test_export_map_records():
     assert (rec["id"][:L] == ctx.get_landmark_ids()).all() and (rec["id"][L:] == -1).all()
     assert np.allclose(rec["x"][:L], mu[3::3]) and np.allclose(rec["theta"][:L], mu[5::3])
     assert np.allclose(rec["S"][0].reshape(3, 3), S[3:6, 3:6])
+
+
+def test_cfg3_general_chain_50_markers():
+    """BASELINE config 3 (1920x1080, 50 markers/frame): more than 24 fused updates per frame -> general 5-kernel EKF chain"""
+    cfg = synth.CONFIGS["cfg3"]
+    stats, ctx, o = pc.run_slam_sequence(cfg, 20, batch=10, literal=False, ctx_kwargs=dict(max_updates_per_frame=64))
+    assert stats["landmarks"] == 100                      # two panels of 50 entered the map
+    assert stats["max_sigma"] < pc.TIGHT
+
+
+def test_cfg5_detect_batch_64_frames():
+    """BASELINE config 5: 64 x 640x480 frames, 4 markers each, detect + PnP only, through aslam_detect_batch (host frames in)"""
+    rows, cols, f = 480, 640, 450.0
+    D = np.zeros(5)
+    ctx = capi.Context(max_rows=rows, max_cols=cols, max_batch=64, max_landmarks=8)
+    frames, expect = [], []
+    K = None
+    for i in range(64):
+        ids, poses, K = synth.simple_scene(rows, cols, f, 4, seed=i)
+        frames.append(ctx.synth_render(i, rows, cols, K, ids, poses, noise_amp=2, seed=100 + i))
+        expect.append(sorted(ids.tolist()))
+    ctx.set_camera(K, D)
+    counts, ids_g, corners_g, rv_g, tv_g = ctx.detect_batch(np.stack(frames), max_per_frame=16)
+    for i in range(64):
+        ids_o, c_o = orc.detect(frames[i])
+        n = counts[i]
+        assert np.array_equal(ids_o, ids_g[i, :n]) and np.array_equal(c_o, corners_g[i, :n])
+        assert sorted(ids_o.tolist()) == expect[i]
+        if i % 8 == 0:
+            pc.check_poses(ids_o, c_o, rv_g[i, :n], tv_g[i, :n], K, D)
