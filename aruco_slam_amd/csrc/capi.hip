@@ -261,6 +261,16 @@ int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool 
         prof_begin(c, P_EKF_APPLY, st);
         launch_ekf_apply(st, c->ekf);
         prof_end(c);
+    } else if (c->init.max_updates_per_frame <= ekf_mid_max_updates()) {
+        prof_begin(c, P_EKF_MID, st);
+        launch_ekf_mid64(st, c->ekf);
+        prof_end(c);
+        prof_begin(c, P_EKF_T, st);
+        launch_ekf_T(st, c->ekf);
+        prof_end(c);
+        prof_begin(c, P_EKF_UPDATE, st);
+        launch_ekf_update_mfma(st, c->ekf);
+        prof_end(c);
     } else {
         prof_begin(c, P_EKF_GATHER, st);
         launch_ekf_gather(st, c->ekf);
@@ -272,7 +282,7 @@ int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool 
         launch_ekf_T(st, c->ekf);
         prof_end(c);
         prof_begin(c, P_EKF_UPDATE, st);
-        launch_ekf_update(st, c->ekf);
+        launch_ekf_update_mfma(st, c->ekf);
         prof_end(c);
     }
     HIP_TRY(c, hipGetLastError());

@@ -55,6 +55,9 @@ void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, do
 void launch_ekf_mid(hipStream_t st, const EkfState& E);
 void launch_ekf_apply(hipStream_t st, const EkfState& E);
 int ekf_fast_max_updates();
+int ekf_mid_max_updates();
+void launch_ekf_mid64(hipStream_t st, const EkfState& E);
+void launch_ekf_update_mfma(hipStream_t st, const EkfState& E);
 void launch_ekf_gather(hipStream_t st, const EkfState& E);
 void launch_ekf_small(hipStream_t st, const EkfState& E);
 void launch_ekf_T(hipStream_t st, const EkfState& E);

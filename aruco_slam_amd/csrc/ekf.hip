@@ -1012,6 +1012,236 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
     }
 }
 
+// =============================================================================================================
+// Medium chain (25 .. 64 fused updates per frame, e.g. the 50-marker / 1000-landmark configuration):
+//   plan -> k_ekf_mid64 -> k_ekf_T -> k_ekf_update_mfma.
+// k_ekf_mid64 is the register-resident block Gauss-Jordan of k_ekf_mid with up to 2 x 2 blocks per thread (32 x 32
+// threads); k_ekf_update_mfma is the rank-3M covariance correction on the f64 matrix cores: at N = 3003, M = 50 it IS a
+// dense contraction (2.7 GFLOP and 144 MB of Sigma traffic per frame).
+// =============================================================================================================
+constexpr int kMidM = 64;
+
+__global__ __launch_bounds__(1024) void k_ekf_mid64(EkfState E) {
+    __shared__ double sCol[2][kMidM][9];
+    __shared__ double sY[kMidM][9];
+    __shared__ double sPinv[9];
+    __shared__ double sZe[3 * kMidM], sNu[3 * kMidM];
+    __shared__ double sPart[kMidM][kMidM][3];
+    const int tid = threadIdx.x;
+    const int m = *E.d_m;
+    const int ld = E.ld;
+    if (m <= 0 || m > kMidM) return;                   // uniform
+    const int n3 = 3 * m;
+    if (blockIdx.x > 0) {
+        // ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns) ----
+        const int N = 3 + 3 * (*E.d_L);
+        const int ncg = (ld + 1023) / 1024;
+        const int gb = blockIdx.x - 1;
+        const int t = (gb % ncg) * 1024 + tid;
+        const int slice = gb / ncg, nslices = (gridDim.x - 1) / ncg;
+        if (t < N) {
+            const double* col = E.d_sigma + (size_t)t * ld;
+            const double c0 = col[0], c1 = col[1], c2 = col[2];
+            const double r0 = E.d_sigma[t], r1 = E.d_sigma[(size_t)ld + t], r2 = E.d_sigma[(size_t)2 * ld + t];
+            for (int k = slice; k < m; k += nslices) {
+                const UpdRec& u = E.d_upd[k];
+                const int li = u.li;
+                const double l0 = col[li], l1 = col[li + 1], l2 = col[li + 2];
+                const double q0 = E.d_sigma[(size_t)li * ld + t], q1 = E.d_sigma[(size_t)(li + 1) * ld + t],
+                             q2 = E.d_sigma[(size_t)(li + 2) * ld + t];
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const double* g = &u.Gxm[a * 6];
+                    E.d_V[(size_t)(3 * k + a) * ld + t] = g[0] * c0 + g[1] * c1 + g[2] * c2 + g[3] * l0 + g[4] * l1 + g[5] * l2;
+                    E.d_Wt[(size_t)(3 * k + a) * ld + t] = r0 * g[0] + r1 * g[1] + r2 * g[2] + q0 * g[3] + q1 * g[4] + q2 * g[5];
+                }
+            }
+        }
+        return;
+    }
+    // ---- workgroup 0: thread (ti, tj) owns the blocks (ti + 32 ii, tj + 32 jj), ii, jj in {0, 1} ----
+    const int tj = tid & 31, ti = tid >> 5;
+    double A[2][2][9];
+    for (int r = tid; r < n3; r += 1024) { const double z = E.d_upd[r / 3].ze[r % 3]; sZe[r] = z; sNu[r] = z; }
+#pragma unroll
+    for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int bi = ti + 32 * ii, bj = tj + 32 * jj;
+            if (bi < m && bj < m) {
+                const UpdRec& ui = E.d_upd[bi];
+                const UpdRec& uj = E.d_upd[bj];
+                const int li = ui.li, lj = uj.li;
+                double S[36];
+#pragma unroll
+                for (int p = 0; p < 6; p++)
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        const int r = p < 3 ? p : li + p - 3, c = q < 3 ? q : lj + q - 3;
+                        S[p * 6 + q] = E.d_sigma[(size_t)c * ld + r];
+                    }
+                double HP[18];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        double s = 0;
+#pragma unroll
+                        for (int p = 0; p < 6; p++) s += ui.Gxm[a * 6 + p] * S[p * 6 + q];
+                        HP[a * 6 + q] = s;
+                    }
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        double s = 0;
+#pragma unroll
+                        for (int q = 0; q < 6; q++) s += HP[a * 6 + q] * uj.Gxm[b * 6 + q];
+                        A[ii][jj][a * 3 + b] = s;
+                    }
+                if (bi == bj) { A[ii][jj][0] += ui.r[0]; A[ii][jj][4] += ui.r[1]; A[ii][jj][8] += ui.r[2]; }
+                if (bj == 0) { for (int k = 0; k < 9; k++) sCol[0][bi][k] = A[ii][jj][k]; }
+                if (bi == 0 && bj == 0) {
+                    double Pn[9];
+                    inv3_reg(A[ii][jj], Pn);
+                    for (int k = 0; k < 9; k++) sPinv[k] = Pn[k];
+                }
+            }
+        }
+    __syncthreads();
+    for (int ib = 0; ib < m; ib++) {
+        const int cb = ib & 1;
+        // phase 1: the pivot row: Y_bj = S_ib^-1 * A(ib, bj)  (S_ib^-1 itself at bj == ib)
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int bi = ti + 32 * ii, bj = tj + 32 * jj;
+                if (bi == ib && bj < m) {
+                    double Pi[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) Pi[k] = sPinv[k];
+                    if (bj == ib) {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) A[ii][jj][k] = Pi[k];
+                    } else {
+                        double Y[9];
+                        mul3(Pi, A[ii][jj], Y);
+#pragma unroll
+                        for (int k = 0; k < 9; k++) A[ii][jj][k] = Y[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 9; k++) sY[bj][k] = A[ii][jj][k];
+                    if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[ii][jj][k]; }
+                }
+            }
+        __syncthreads();
+        // phase 2: every other block: A(bi, bj) -= F * Y_bj with F = A(bi, ib) before this step
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int bi = ti + 32 * ii, bj = tj + 32 * jj;
+                if (bi < m && bj < m && bi != ib) {
+                    double F[9], Y[9], X[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) { F[k] = sCol[cb][bi][k]; Y[k] = sY[bj][k]; }
+                    mul3(F, Y, X);
+                    if (bj == ib) {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) A[ii][jj][k] = -X[k];
+                        if (bi > ib) {
+                            const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
+#pragma unroll
+                            for (int a = 0; a < 3; a++) sNu[3 * bi + a] += X[a * 3] * z0 + X[a * 3 + 1] * z1 + X[a * 3 + 2] * z2;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 9; k++) A[ii][jj][k] -= X[k];
+                    }
+                    if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[ii][jj][k]; }
+                    if (bi == ib + 1 && bj == ib + 1) {
+                        double Pn[9];
+                        inv3_reg(A[ii][jj], Pn);
+#pragma unroll
+                        for (int k = 0; k < 9; k++) sPinv[k] = Pn[k];
+                    }
+                }
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int bi = ti + 32 * ii, bj = tj + 32 * jj;
+            if (bi < m && bj < m) {
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) E.d_G[(size_t)(3 * bi + a) * n3 + 3 * bj + b] = A[ii][jj][a * 3 + b];
+                const double n0 = sNu[3 * bj], n1 = sNu[3 * bj + 1], n2 = sNu[3 * bj + 2];
+#pragma unroll
+                for (int a = 0; a < 3; a++) sPart[bi][bj][a] = A[ii][jj][a * 3] * n0 + A[ii][jj][a * 3 + 1] * n1 + A[ii][jj][a * 3 + 2] * n2;
+            }
+        }
+    __syncthreads();
+    for (int r = tid; r < n3; r += 1024) {
+        const int i = r / 3, a = r - 3 * i;
+        double s = 0;
+        for (int j = 0; j < m; j++) s += sPart[i][j][a];
+        E.d_g[r] = s;
+    }
+}
+
+// Sigma <- Sigma - W T on the f64 matrix cores.  One wavefront owns a 64 x 64 tile of Sigma as 4 x 4 tiles of
+// v_mfma_f64_16x16x4_f64; the tile is formed transposed, D'[c][r] = sum_p T[p][c] W^T[p][r], so that every accumulator
+// register maps to 16 consecutive rows r of one column c: the read-modify-write of the column-major Sigma is coalesced.
+// Operand layout (cdna_hip_programming.md §3): A[i][k] in lane k*16+i, B[k][j] in lane k*16+j, D rows (lane>>4)+4*reg, col lane&15.
+typedef double v4d __attribute__((vector_size(4 * sizeof(double))));
+
+__global__ __launch_bounds__(256) void k_ekf_update_mfma(EkfState E) {
+    const int m = *E.d_m;
+    if (m <= 0) return;
+    const int n3 = 3 * m;
+    const int N = 3 + 3 * (*E.d_L);
+    const int ld = E.ld;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = blockIdx.y * 128 + (wave >> 1) * 64;          // columns of Sigma (i index of D')
+    const int r0 = blockIdx.x * 128 + (wave & 1) * 64;           // rows of Sigma (j index of D')
+    if (c0 >= N || r0 >= N) return;                               // uniform per wavefront (no workgroup barrier in this kernel)
+    const int li = lane & 15, lk = lane >> 4;
+    v4d acc[4][4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ci++)
+#pragma unroll
+        for (int ri = 0; ri < 4; ri++) acc[ci][ri] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < n3; p0 += 4) {
+        const int p = p0 + lk;
+        const bool pin = p < n3;
+        double a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = c0 + 16 * q + li, r = r0 + 16 * q + li;
+            a[q] = (pin && c < N) ? E.d_T[(size_t)p * ld + c] : 0.0;
+            b[q] = (pin && r < N) ? E.d_Wt[(size_t)p * ld + r] : 0.0;
+        }
+#pragma unroll
+        for (int ci = 0; ci < 4; ci++)
+#pragma unroll
+            for (int ri = 0; ri < 4; ri++) acc[ci][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ci], b[ri], acc[ci][ri], 0, 0, 0);
+    }
+#pragma unroll
+    for (int ci = 0; ci < 4; ci++)
+#pragma unroll
+        for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int c = c0 + 16 * ci + lk + 4 * reg, r = r0 + 16 * ri + li;
+                if (c < N && r < N) E.d_sigma[(size_t)c * ld + r] -= acc[ci][ri][reg];
+            }
+}
+
 __global__ __launch_bounds__(256) void k_ekf_export_map(EkfState E) {
     const int L = *E.d_L;
     const int ld = E.ld;
@@ -1113,6 +1343,15 @@ void launch_ekf_apply(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_apply, dim3(t, t), dim3(256), 0, st, E);
 }
 int ekf_fast_max_updates() { return kFastM; }
+int ekf_mid_max_updates() { return kMidM; }
+void launch_ekf_mid64(hipStream_t st, const EkfState& E) {
+    const int ncg = (E.ld + 1023) / 1024;
+    hipLaunchKernelGGL(k_ekf_mid64, dim3(1 + ncg * 16), dim3(1024), 0, st, E);
+}
+void launch_ekf_update_mfma(hipStream_t st, const EkfState& E) {
+    const int t = (E.ld + 127) / 128;
+    hipLaunchKernelGGL(k_ekf_update_mfma, dim3(t, t), dim3(256), 0, st, E);
+}
 void launch_ekf_export_map(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_export_map, dim3((E.max_landmarks + 255) / 256), dim3(256), 0, st, E);
 }

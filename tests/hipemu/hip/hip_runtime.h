@@ -48,6 +48,7 @@ struct Lane {
 };
 struct WaveCtx {
     unsigned long long slot[64];
+    unsigned long long slot2[64];
     int lanes = 0;        // lanes that exist
     int live = 0;         // lanes that have not returned yet
     int arrived = 0;
@@ -125,6 +126,25 @@ inline unsigned long long __ballot(int pred) {
     for (int i = 0; i < w.lanes; i++) m |= (w.slot[i] & 1ull) << i;
     hipemu::wave_sync();
     return m;
+}
+// v_mfma_f64_16x16x4_f64: A[i][k] from lane k*16+i, B[k][j] from lane k*16+j, D rows (lane>>4)+4*reg, column lane&15
+typedef double hipemu_v4d __attribute__((vector_size(4 * sizeof(double))));
+inline hipemu_v4d __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipemu_v4d c, int, int, int) {
+    hipemu::WaveCtx& w = hipemu::wave();
+    const int me = hipemu::t_lane;
+    w.slot[me] = hipemu::to_bits(a);
+    w.slot2[me] = hipemu::to_bits(b);
+    hipemu::wave_sync();
+    hipemu_v4d d = c;
+    const int col = me & 15;
+    for (int reg = 0; reg < 4; reg++) {
+        const int row = (me >> 4) + 4 * reg;
+        double s = c[reg];
+        for (int k = 0; k < 4; k++) s += hipemu::from_bits<double>(w.slot[k * 16 + row]) * hipemu::from_bits<double>(w.slot2[k * 16 + col]);
+        d[reg] = s;
+    }
+    hipemu::wave_sync();
+    return d;
 }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -69,6 +69,15 @@ def test_device_ekf_general_chain():
     replay(GOLDEN[2], batch=1, max_updates=64)
 
 
+def test_device_ekf_medium_chain():
+    """25 .. 64 updates per frame: register-block Gauss-Jordan with 2 x 2 blocks per thread + the f64 MFMA covariance update"""
+    replay(GOLDEN[2], batch=1, max_updates=48)
+
+
+def test_device_ekf_general_chain_above_64():
+    replay(GOLDEN[1], batch=1, max_updates=100)
+
+
 def test_too_many_updates_is_reported():
     with pytest.raises(capi.AslamError) as e:
         replay(GOLDEN[2], batch=1, max_updates=4)
@@ -81,3 +90,4 @@ def test_device_ekf_replays_golden_on_gpu(path):
     replay(path, batch=1)
     replay(path, batch=4)
     replay(path, batch=3, max_updates=64)
+    replay(path, batch=2, max_updates=100)
