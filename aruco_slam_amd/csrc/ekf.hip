@@ -1200,36 +1200,63 @@ __global__ __launch_bounds__(1024) void k_ekf_mid64(EkfState E) {
 // Operand layout (cdna_hip_programming.md §3): A[i][k] in lane k*16+i, B[k][j] in lane k*16+j, D rows (lane>>4)+4*reg, col lane&15.
 typedef double v4d __attribute__((vector_size(4 * sizeof(double))));
 
+constexpr int MUK = 16;                  // depth rows of T / W^T staged per chunk
+
 __global__ __launch_bounds__(256) void k_ekf_update_mfma(EkfState E) {
+    __shared__ double sT[2][MUK][128];
+    __shared__ double sW[2][MUK][128];
     const int m = *E.d_m;
     if (m <= 0) return;
     const int n3 = 3 * m;
     const int N = 3 + 3 * (*E.d_L);
     const int ld = E.ld;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c0 = blockIdx.y * 128 + (wave >> 1) * 64;          // columns of Sigma (i index of D')
-    const int r0 = blockIdx.x * 128 + (wave & 1) * 64;           // rows of Sigma (j index of D')
-    if (c0 >= N || r0 >= N) return;                               // uniform per wavefront (no workgroup barrier in this kernel)
+    const int cb0 = blockIdx.y * 128, rb0 = blockIdx.x * 128;     // workgroup tile: columns cb0.., rows rb0.. of Sigma
+    if (cb0 >= N || rb0 >= N) return;                              // uniform per workgroup
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wc = (wave >> 1) * 64, wr = (wave & 1) * 64;        // this wavefront's 64 x 64 sub-tile
     const int li = lane & 15, lk = lane >> 4;
     v4d acc[4][4];
 #pragma unroll
     for (int ci = 0; ci < 4; ci++)
 #pragma unroll
         for (int ri = 0; ri < 4; ri++) acc[ci][ri] = v4d{0.0, 0.0, 0.0, 0.0};
-    for (int p0 = 0; p0 < n3; p0 += 4) {
-        const int p = p0 + lk;
-        const bool pin = p < n3;
-        double a[4], b[4];
+
+    // chunk loader: MUK x 128 doubles of T and of W^T = 8 + 8 values per thread, issued in bulk
+    const int lx = tid & 127, lp = tid >> 7;                      // column within the tile, depth row parity (0/1)
+    double pt[8], pw[8];
+    const int nchunks = (n3 + MUK - 1) / MUK;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = c0 + 16 * q + li, r = r0 + 16 * q + li;
-            a[q] = (pin && c < N) ? E.d_T[(size_t)p * ld + c] : 0.0;
-            b[q] = (pin && r < N) ? E.d_Wt[(size_t)p * ld + r] : 0.0;
+    for (int k = 0; k < 8; k++) {
+        const int p = lp + 2 * k;
+        pt[k] = (p < n3 && cb0 + lx < N) ? E.d_T[(size_t)p * ld + cb0 + lx] : 0.0;
+        pw[k] = (p < n3 && rb0 + lx < N) ? E.d_Wt[(size_t)p * ld + rb0 + lx] : 0.0;
+    }
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int buf = ch & 1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { sT[buf][lp + 2 * k][lx] = pt[k]; sW[buf][lp + 2 * k][lx] = pw[k]; }
+        __syncthreads();
+        if (ch + 1 < nchunks) {                                    // prefetch the next chunk while this one is multiplied
+            const int pb = (ch + 1) * MUK;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int p = pb + lp + 2 * k;
+                pt[k] = (p < n3 && cb0 + lx < N) ? E.d_T[(size_t)p * ld + cb0 + lx] : 0.0;
+                pw[k] = (p < n3 && rb0 + lx < N) ? E.d_Wt[(size_t)p * ld + rb0 + lx] : 0.0;
+            }
         }
 #pragma unroll
-        for (int ci = 0; ci < 4; ci++)
+        for (int kk = 0; kk < MUK / 4; kk++) {
+            double a[4], b[4];
 #pragma unroll
-            for (int ri = 0; ri < 4; ri++) acc[ci][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ci], b[ri], acc[ci][ri], 0, 0, 0);
+            for (int q = 0; q < 4; q++) { a[q] = sT[buf][kk * 4 + lk][wc + 16 * q + li]; b[q] = sW[buf][kk * 4 + lk][wr + 16 * q + li]; }
+#pragma unroll
+            for (int ci = 0; ci < 4; ci++)
+#pragma unroll
+                for (int ri = 0; ri < 4; ri++) acc[ci][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ci], b[ri], acc[ci][ri], 0, 0, 0);
+        }
+        // the other buffer is rewritten next iteration: every wave has finished reading it one iteration ago (barrier above)
     }
 #pragma unroll
     for (int ci = 0; ci < 4; ci++)
@@ -1237,7 +1264,7 @@ __global__ __launch_bounds__(256) void k_ekf_update_mfma(EkfState E) {
         for (int ri = 0; ri < 4; ri++)
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int c = c0 + 16 * ci + lk + 4 * reg, r = r0 + 16 * ri + li;
+                const int c = cb0 + wc + 16 * ci + lk + 4 * reg, r = rb0 + wr + 16 * ri + li;
                 if (c < N && r < N) E.d_sigma[(size_t)c * ld + r] -= acc[ci][ri][reg];
             }
 }
