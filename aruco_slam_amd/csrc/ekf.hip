@@ -907,10 +907,16 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
 
 constexpr int APK = kFastN3;             // padded depth of the LDS images (72)
 
+typedef double v4d __attribute__((vector_size(4 * sizeof(double))));
+
+// f64 matrix cores (v_mfma_f64_16x16x4_f64) for both products of the tile.  Operand layout (cdna_hip_programming.md §3):
+// A[i][k] in lane k*16+i, B[k][j] in lane k*16+j, D rows (lane>>4)+4*reg, column lane&15.  The Sigma tile is formed
+// transposed, D'[c][r] = sum_p T[p][c] W^T[p][r], so each accumulator register covers 16 consecutive rows r of one
+// column c and the read-modify-write of the column-major Sigma is coalesced.
 __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
-    __shared__ double sGt[APK * APK];         // G transposed: sGt[p][q], row stride APK, zero padded
+    __shared__ double sGt[APK * APK + 16];    // G transposed: sGt[p][q], row stride APK, zero padded (+16: the 5th q-tile reads 8 past)
     __shared__ double sVW[APK][64];           // V tile, later the W^T tile
-    __shared__ double sT[APK][64];            // T tile = G V tile
+    __shared__ double sT[APK + 8][64];        // T tile = G V tile (rows 72..79 belong to the padded 5th q-tile)
     __shared__ double sg[APK];
     const int m = *E.d_m;
     if (m <= 0 || m > kFastM) return;         // uniform
@@ -920,17 +926,19 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     if (r0 >= N || c0 >= N) return;           // uniform
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;                   // 16 x 16 threads, 4 x 4 outputs each
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
 
     // Every global load of the workgroup is issued up front (Sigma tile, G, V tile, W^T tile: ~75 loads per thread in
     // flight) so the kernel pays the dependent-launch memory latency once, not once per staging loop.
-    double sig[16];
+    // Sigma tile in the accumulator layout of the update: wave = column tile, ri = row tile, reg
+    double sig[4][4];
 #pragma unroll
-    for (int jc = 0; jc < 4; jc++)
+    for (int ri = 0; ri < 4; ri++)
 #pragma unroll
-        for (int jr = 0; jr < 4; jr++) {
-            const int rr = r0 + 4 * tx + jr, c = c0 + 4 * ty + jc;
-            sig[jc * 4 + jr] = (rr < N && c < N) ? E.d_sigma[(size_t)c * ld + rr] : 0.0;
+        for (int reg = 0; reg < 4; reg++) {
+            const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
+            sig[ri][reg] = (r < N && c < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
         }
     constexpr int NG = (APK * APK + 255) / 256;      // 21
     constexpr int NV = APK * 64 / 256;               // 18
@@ -949,62 +957,60 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
         tw[k] = (pq < n3 && r0 + xx < N) ? E.d_Wt[(size_t)pq * ld + r0 + xx] : 0.0;
     }
     const double gval = (tid < APK && tid < n3) ? E.d_g[tid] : 0.0;
-    // G transposed into LDS (sGt[p][q] = G[q][p], zero padded to APK x APK) and the V tile
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         const int i = tid + 256 * k;
         const int q = i / APK, pq = i - q * APK;
         if (i < APK * APK) sGt[pq * APK + q] = tg[k];
     }
+    if (tid < 16) sGt[APK * APK + tid] = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) { const int i = tid + 256 * k; sVW[i >> 6][i & 63] = tv[k]; }
     if (tid < APK) sg[tid] = gval;
     __syncthreads();
-    // T tile (72 x 64): thread (qg, xg) forms a 9 x 2 register tile: rows 9*qg .. +8, columns 2*xg, 2*xg+1
+
+    // T tile (80 x 64, rows >= 72 unused): wave w owns columns 16w .. 16w+15 and all five 16-row tiles
     {
-        const int xg = tid & 31, qg = tid >> 5;               // 32 x 8
-        double acc[18];
+        v4d acc[5];
 #pragma unroll
-        for (int j = 0; j < 18; j++) acc[j] = 0.0;
-        for (int pq = 0; pq < n3; pq++) {
-            const double v0 = sVW[pq][2 * xg], v1 = sVW[pq][2 * xg + 1];
+        for (int qi = 0; qi < 5; qi++) acc[qi] = v4d{0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < APK; p0 += 4) {
+            const double bfrag = sVW[p0 + lk][16 * wave + li];                       // B[k = p][j = x] = V[p][x]
 #pragma unroll
-            for (int j = 0; j < 9; j++) {
-                const double gq = sGt[pq * APK + 9 * qg + j];
-                acc[2 * j] += gq * v0;
-                acc[2 * j + 1] += gq * v1;
+            for (int qi = 0; qi < 5; qi++) {
+                const double afrag = sGt[(p0 + lk) * APK + 16 * qi + li];           // A[i = q][k = p] = G[q][p]
+                acc[qi] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag, bfrag, acc[qi], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 9; j++) { sT[9 * qg + j][2 * xg] = acc[2 * j]; sT[9 * qg + j][2 * xg + 1] = acc[2 * j + 1]; }
+        for (int qi = 0; qi < 5; qi++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) sT[16 * qi + lk + 4 * reg][16 * wave + li] = acc[qi][reg];
     }
     __syncthreads();
     // W^T tile (already in registers) replaces the V tile
 #pragma unroll
     for (int k = 0; k < NV; k++) { const int i = tid + 256 * k; sVW[i >> 6][i & 63] = tw[k]; }
     __syncthreads();
-    // Sigma tile -= W_tile^T T_tile : thread (tx, ty) owns rows 4*tx .. +3, columns 4*ty .. +3
-    double acc[16];
+    // Sigma tile, transposed product: wave w owns the 16 columns c0 + 16w .. and all four 16-row tiles
+    v4d acc[4];
 #pragma unroll
-    for (int j = 0; j < 16; j++) acc[j] = 0.0;
-    for (int pq = 0; pq < n3; pq++) {
-        double w[4], t[4];
+    for (int ri = 0; ri < 4; ri++) acc[ri] = v4d{0.0, 0.0, 0.0, 0.0};
+    for (int p0 = 0; p0 < APK; p0 += 4) {
+        const double afrag = sT[p0 + lk][16 * wave + li];                            // A[i = c][k = p] = T[p][c]
 #pragma unroll
-        for (int k = 0; k < 4; k++) { w[k] = sVW[pq][4 * tx + k]; t[k] = sT[pq][4 * ty + k]; }
-#pragma unroll
-        for (int jc = 0; jc < 4; jc++)
-#pragma unroll
-            for (int jr = 0; jr < 4; jr++) acc[jc * 4 + jr] += w[jr] * t[jc];
-    }
-#pragma unroll
-    for (int jc = 0; jc < 4; jc++) {
-        const int c = c0 + 4 * ty + jc;
-#pragma unroll
-        for (int jr = 0; jr < 4; jr++) {
-            const int rr = r0 + 4 * tx + jr;
-            if (rr < N && c < N) E.d_sigma[(size_t)c * ld + rr] = sig[jc * 4 + jr] - acc[jc * 4 + jr];
+        for (int ri = 0; ri < 4; ri++) {
+            const double bfrag = sVW[p0 + lk][16 * ri + li];                         // B[k = p][j = r] = W^T[p][r]
+            acc[ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(afrag, bfrag, acc[ri], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
+            if (r < N && c < N) E.d_sigma[(size_t)c * ld + r] = sig[ri][reg] - acc[ri][reg];
+        }
     if (blockIdx.y == 0 && tid < 64 && r0 + tid < N) {
         double s0 = 0, s1 = 0;
         for (int pq = 0; pq < n3; pq += 2) { s0 += sVW[pq][tid] * sg[pq]; s1 += sVW[pq + 1][tid] * sg[pq + 1]; }
@@ -1198,7 +1204,6 @@ __global__ __launch_bounds__(1024) void k_ekf_mid64(EkfState E) {
 // v_mfma_f64_16x16x4_f64; the tile is formed transposed, D'[c][r] = sum_p T[p][c] W^T[p][r], so that every accumulator
 // register maps to 16 consecutive rows r of one column c: the read-modify-write of the column-major Sigma is coalesced.
 // Operand layout (cdna_hip_programming.md §3): A[i][k] in lane k*16+i, B[k][j] in lane k*16+j, D rows (lane>>4)+4*reg, col lane&15.
-typedef double v4d __attribute__((vector_size(4 * sizeof(double))));
 
 constexpr int MUK = 16;                  // depth rows of T / W^T staged per chunk
 
