@@ -247,32 +247,21 @@ int run_detect(aslam_ctx* c, int first, int count) {
     return ASLAM_OK;
 }
 
-struct FrameEnc { int slot; double wl, wr, dt; bool predict; };
-
-// One EKF step.  `planned` = the plan of this frame was already executed by the previous frame's k_ekf_apply;
-// `next` (may be null) = the frame whose plan this frame's k_ekf_apply should run when it finishes (fast chain only).
-int run_ekf_frame(aslam_ctx* c, const FrameEnc& fr, bool planned, const FrameEnc* next) {
+int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool do_predict) {
     hipStream_t st = c->stream_ekf;
     const bool fast = c->init.max_updates_per_frame <= ekf_fast_max_updates();
-    const int max_m = c->init.max_updates_per_frame;
-    if (!planned) {
-        prof_begin(c, P_EKF_PLAN, st);
-        launch_ekf_plan(st, c->ekf, c->sp, fr.wl, fr.wr, fr.dt, fr.predict ? 1 : 0, c->d_obs + (size_t)fr.slot * kMarkerMax,
-                        c->d_nmarkers + fr.slot, c->d_ctr, max_m);
-        prof_end(c);
-    }
+    prof_begin(c, P_EKF_PLAN, st);
+    launch_ekf_plan(st, c->ekf, c->sp, wl, wr, dt, do_predict ? 1 : 0, c->d_obs + (size_t)slot * kMarkerMax, c->d_nmarkers + slot, c->d_ctr,
+                    c->init.max_updates_per_frame);
+    prof_end(c);
     if (fast) {
         prof_begin(c, P_EKF_MID, st);
         launch_ekf_mid(st, c->ekf);
         prof_end(c);
         prof_begin(c, P_EKF_APPLY, st);
-        if (next)
-            launch_ekf_apply(st, c->ekf, c->sp, 1, next->wl, next->wr, next->dt, next->predict ? 1 : 0,
-                             c->d_obs + (size_t)next->slot * kMarkerMax, c->d_nmarkers + next->slot, c->d_ctr, max_m);
-        else
-            launch_ekf_apply(st, c->ekf, c->sp, 0, 0, 0, 0, 0, nullptr, nullptr, c->d_ctr, max_m);
+        launch_ekf_apply(st, c->ekf);
         prof_end(c);
-    } else if (max_m <= ekf_mid_max_updates()) {
+    } else if (c->init.max_updates_per_frame <= ekf_mid_max_updates()) {
         prof_begin(c, P_EKF_MID, st);
         launch_ekf_mid64(st, c->ekf);
         prof_end(c);
@@ -486,17 +475,12 @@ int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
     if (with_ekf) {
         if (c->enc_host.size() < (size_t)3 * (first + count)) return fail(c, ASLAM_E_STATE, "encoders not staged");
         HIP_TRY(c, hipStreamWaitEvent(c->stream_ekf, c->ev_detect, 0));
-        const bool fast = c->init.max_updates_per_frame <= ekf_fast_max_updates();
-        std::vector<FrameEnc> fe(count);
         for (int i = 0; i < count; i++) {
             const double* e = &c->enc_host[(size_t)3 * (first + i)];
             // addEncoder semantics (aruco_slam.cpp:24-29): the very first sample only arms the filter
-            fe[i] = FrameEnc{first + i, e[0], e[1], e[2], c->is_init};
+            bool predict = c->is_init;
             c->is_init = true;
-        }
-        for (int i = 0; i < count; i++) {
-            // fast chain: frame i's k_ekf_apply also runs frame i+1's plan (one dependent launch less per frame)
-            r = run_ekf_frame(c, fe[i], fast && i > 0, (fast && i + 1 < count) ? &fe[i + 1] : nullptr);
+            r = run_ekf_frame(c, first + i, e[0], e[1], e[2], predict);
             if (r) return r;
         }
         HIP_TRY(c, hipEventRecord(c->ev_ekf, c->stream_ekf));
@@ -533,7 +517,7 @@ int aslam_add_image(aslam_ctx* c, const uint8_t* px, int rows, int cols, int cha
     r = run_detect(c, 0, 1);
     if (r) return r;
     HIP_TRY(c, hipStreamWaitEvent(c->stream_ekf, c->ev_detect, 0));
-    r = run_ekf_frame(c, FrameEnc{0, 0, 0, 0, false}, false, nullptr);
+    r = run_ekf_frame(c, 0, 0, 0, 0, false);
     if (r) return r;
     return sync_and_check(c);
 }

@@ -42,7 +42,6 @@ struct EkfState {
     int* d_npop;
     UpdRec* d_upd;
     int* d_m;                          // fused updates this frame
-    unsigned* d_done;                  // arrival counter of k_ekf_apply's workgroups (last one runs the next frame's plan)
     double *d_V, *d_Wt, *d_T;          // 3m x ld each, row k contiguous
     double *d_Sv, *d_Sw, *d_alpha, *d_gamma, *d_G, *d_g;
     MapRecord* d_maprec;
@@ -54,8 +53,7 @@ void launch_ekf_predict_only(hipStream_t st, const EkfState& E, const SlamParams
 void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int do_predict,
                      const ObsRaw* obs, const unsigned* n_markers, Counters* ctr, int max_m);
 void launch_ekf_mid(hipStream_t st, const EkfState& E);
-void launch_ekf_apply(hipStream_t st, const EkfState& E, const SlamParams& sp, int has_next, double wl, double wr, double dt,
-                      int do_predict, const ObsRaw* obs, const unsigned* n_markers, Counters* ctr, int max_m);
+void launch_ekf_apply(hipStream_t st, const EkfState& E);
 int ekf_fast_max_updates();
 int ekf_mid_max_updates();
 void launch_ekf_mid64(hipStream_t st, const EkfState& E);

@@ -106,10 +106,10 @@ __global__ __launch_bounds__(256) void k_ekf_predict(EkfState E, SlamParams sp, 
     predict_block(E, sp, wl, wr, dt, N, sH, sQ, sMu);
 }
 
-// ---- plan: predict + queue order + augment + update plan (one workgroup of 256 threads) -----------------------
-__device__ void plan_body(const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int do_predict,
-                          const ObsRaw* __restrict__ obs, const unsigned* __restrict__ n_markers,
-                          Counters* ctr, int max_m) {
+// ---- plan: predict + queue order + augment + update plan (one workgroup) -----------------------------------
+__global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, double wl, double wr, double dt, int do_predict,
+                                                  const ObsRaw* __restrict__ obs, const unsigned* __restrict__ n_markers,
+                                                  Counters* ctr, int max_m) {
     __shared__ double sH[9], sQ[9], sMu[3];
     __shared__ ObsRaw sObs[kMarkerMax];
     __shared__ LastObs sLast[kMarkerMax];
@@ -353,12 +353,6 @@ __device__ void plan_body(const EkfState& E, const SlamParams& sp, double wl, do
         *E.d_L = sL;
         *E.d_m = sM;
     }
-}
-
-__global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, double wl, double wr, double dt, int do_predict,
-                                                  const ObsRaw* __restrict__ obs, const unsigned* __restrict__ n_markers,
-                                                  Counters* ctr, int max_m) {
-    plan_body(E, sp, wl, wr, dt, do_predict, obs, n_markers, ctr, max_m);
 }
 
 // ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns); grid (columns / 256, update slices) -----------
@@ -919,46 +913,18 @@ typedef double v4d __attribute__((vector_size(4 * sizeof(double))));
 // A[i][k] in lane k*16+i, B[k][j] in lane k*16+j, D rows (lane>>4)+4*reg, column lane&15.  The Sigma tile is formed
 // transposed, D'[c][r] = sum_p T[p][c] W^T[p][r], so each accumulator register covers 16 consecutive rows r of one
 // column c and the read-modify-write of the column-major Sigma is coalesced.
-// The workgroup that finishes last (arrival counter behind an agent-scope fence) also runs the NEXT frame's k_ekf_plan
-// body, which needs the finished Sigma and mu: one dependent launch less per frame.
-struct NextPlan {
-    int has_next, do_predict, max_m, pad;
-    double wl, wr, dt;
-    const ObsRaw* obs;
-    const unsigned* n_markers;
-};
-
-__device__ void apply_tile(const EkfState& E, int m, int N, int r0, int c0);
-
-__global__ __launch_bounds__(256) void k_ekf_apply(EkfState E, SlamParams sp, NextPlan np, Counters* ctr) {
-    __shared__ int sIsLast;
-    const int m = *E.d_m;
-    const int N = 3 + 3 * (*E.d_L);
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    if (m > 0 && m <= kFastM && r0 < N && c0 < N) apply_tile(E, m, N, r0, c0);      // uniform per workgroup
-    if (np.has_next) {
-        __threadfence();                                   // release this workgroup's Sigma / mu writes (agent scope)
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned arrived = atomicAdd(E.d_done, 1u);
-            sIsLast = arrived == gridDim.x * gridDim.y - 1u;
-        }
-        __syncthreads();
-        if (sIsLast) {                                     // uniform per workgroup
-            __threadfence();                               // acquire: every other workgroup's writes are visible
-            if (threadIdx.x == 0) *E.d_done = 0u;
-            plan_body(E, sp, np.wl, np.wr, np.dt, np.do_predict, np.obs, np.n_markers, ctr, np.max_m);
-        }
-    }
-}
-
-__device__ void apply_tile(const EkfState& E, int m, int N, int r0, int c0) {
+__global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
     __shared__ double sGt[APK * APK + 16];    // G transposed: sGt[p][q], row stride APK, zero padded (+16: the 5th q-tile reads 8 past)
     __shared__ double sVW[APK][64];           // V tile, later the W^T tile
     __shared__ double sT[APK + 8][64];        // T tile = G V tile (rows 72..79 belong to the padded 5th q-tile)
     __shared__ double sg[APK];
+    const int m = *E.d_m;
+    if (m <= 0 || m > kFastM) return;         // uniform
     const int n3 = 3 * m;
+    const int N = 3 + 3 * (*E.d_L);
     const int ld = E.ld;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    if (r0 >= N || c0 >= N) return;           // uniform
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -1045,7 +1011,7 @@ __device__ void apply_tile(const EkfState& E, int m, int N, int r0, int c0) {
             const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
             if (r < N && c < N) E.d_sigma[(size_t)c * ld + r] = sig[ri][reg] - acc[ri][reg];
         }
-    if (c0 == 0 && tid < 64 && r0 + tid < N) {
+    if (blockIdx.y == 0 && tid < 64 && r0 + tid < N) {
         double s0 = 0, s1 = 0;
         for (int pq = 0; pq < n3; pq += 2) { s0 += sVW[pq][tid] * sg[pq]; s1 += sVW[pq + 1][tid] * sg[pq + 1]; }
         E.d_mu[r0 + tid] += s0 + s1;                              // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
@@ -1349,7 +1315,6 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks) {
     A(dalloc(&E.d_npop, 1));
     A(dalloc(&E.d_upd, kMarkerMax));
     A(dalloc(&E.d_m, 1));
-    A(dalloc(&E.d_done, 1));
     A(dalloc(&E.d_V, n3 * ld));
     A(dalloc(&E.d_Wt, n3 * ld));
     A(dalloc(&E.d_T, n3 * ld));
@@ -1369,14 +1334,13 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks) {
     A(hipMemset(E.d_nlast, 0, sizeof(int)));
     A(hipMemset(E.d_npop, 0, sizeof(int)));
     A(hipMemset(E.d_m, 0, sizeof(int)));
-    A(hipMemset(E.d_done, 0, sizeof(unsigned)));
 #undef A
     return hipSuccess;
 }
 
 void ekf_free(EkfState& E) {
     hipFree(E.d_mu); hipFree(E.d_sigma); hipFree(E.d_L); hipFree(E.d_id2idx); hipFree(E.d_idx2id); hipFree(E.d_last); hipFree(E.d_lastNext);
-    hipFree(E.d_nlast); hipFree(E.d_pop); hipFree(E.d_npop); hipFree(E.d_upd); hipFree(E.d_m); hipFree(E.d_done); hipFree(E.d_V); hipFree(E.d_Wt);
+    hipFree(E.d_nlast); hipFree(E.d_pop); hipFree(E.d_npop); hipFree(E.d_upd); hipFree(E.d_m); hipFree(E.d_V); hipFree(E.d_Wt);
     hipFree(E.d_T); hipFree(E.d_Sv); hipFree(E.d_Sw); hipFree(E.d_alpha); hipFree(E.d_gamma); hipFree(E.d_G); hipFree(E.d_g);
     hipFree(E.d_maprec);
     E = EkfState{};
@@ -1406,13 +1370,9 @@ void launch_ekf_mid(hipStream_t st, const EkfState& E) {
     const int ncg = (E.ld + MIDT - 1) / MIDT;
     hipLaunchKernelGGL(k_ekf_mid, dim3(1 + ncg * 12), dim3(MIDT), 0, st, E);
 }
-void launch_ekf_apply(hipStream_t st, const EkfState& E, const SlamParams& sp, int has_next, double wl, double wr, double dt,
-                      int do_predict, const ObsRaw* obs, const unsigned* n_markers, Counters* ctr, int max_m) {
+void launch_ekf_apply(hipStream_t st, const EkfState& E) {
     const int t = (E.ld + 63) / 64;
-    NextPlan np;
-    np.has_next = has_next; np.do_predict = do_predict; np.max_m = max_m; np.pad = 0;
-    np.wl = wl; np.wr = wr; np.dt = dt; np.obs = obs; np.n_markers = n_markers;
-    hipLaunchKernelGGL(k_ekf_apply, dim3(t, t), dim3(256), 0, st, E, sp, np, ctr);
+    hipLaunchKernelGGL(k_ekf_apply, dim3(t, t), dim3(256), 0, st, E);
 }
 int ekf_fast_max_updates() { return kFastM; }
 int ekf_mid_max_updates() { return kMidM; }
