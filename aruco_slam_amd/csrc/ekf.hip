@@ -748,8 +748,8 @@ __device__ __forceinline__ void mul3(const double* X, const double* Y, double* Z
 
 // <= 128 VGPRs (4 waves per SIMD) so that the workgroup always finds room beside the persistent detection waves of the other stream
 __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
-    __shared__ double sCol[2][kFastM][9];             // pivot column blocks (bi, ib)
-    __shared__ double sY[kFastM][9];                  // S_ib^-1 * pivot row blocks of the current step
+    __shared__ __align__(16) double sCol[2][kFastM][10];   // pivot column blocks (bi, ib); rows padded to 80 B for 128-bit LDS reads
+    __shared__ __align__(16) double sY[kFastM][10];                  // S_ib^-1 * pivot row blocks of the current step
     __shared__ double sPinv[9];                       // S_ib^-1 of the current step (formed at the end of the previous one)
     __shared__ double sZe[kFastN3], sNu[kFastN3];
     __shared__ double sPart[kFastM][kFastM][3];
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
         return;
     }
     // ---- workgroup 0: thread (bi, bj) owns the 3x3 block (bi, bj) of A = H Sigma0 H^T + R in registers ----
-    const int bj = tid % kFastM, bi = tid / kFastM;
+    const int bj = tid % m, bi = tid / m;              // dense m x m mapping: the active threads fill whole waves
     const bool act = bi < m && bj < m;
     double A[9];
     if (tid < n3) { const double z = E.d_upd[tid / 3].ze[tid % 3]; sZe[tid] = z; sNu[tid] = z; }
@@ -856,25 +856,26 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
 #pragma unroll
             for (int k = 0; k < 9; k++) sY[bj][k] = A[k];
             if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[k]; }     // next step's F of this row
+        } else if (act && bj == ib) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) A[k] = 0.0;                                            // pivot column: becomes 0 - F * S^-1
         }
         __syncthreads();
-        // phase 2: every other block: A(bi, bj) -= F * Y_bj with F = A(bi, ib) before this step (0 - F * S^-1 at bj == ib)
+        // phase 2: every other block: A(bi, bj) -= F * Y_bj with F = A(bi, ib) before this step (0 - F * S^-1 at bj == ib:
+        // those blocks were zeroed during phase 1), as three fused multiply-adds per element
         if (act && bi != ib) {
-            double F[9], Y[9], X[9];
+            double F[9], Y[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) { F[k] = sCol[cb][bi][k]; Y[k] = sY[bj][k]; }
-            mul3(F, Y, X);
-            if (bj == ib) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) A[k] = -X[k];
-                if (bi > ib) {
-                    const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
+            for (int i = 0; i < 3; i++)
 #pragma unroll
-                    for (int a = 0; a < 3; a++) sNu[3 * bi + a] += X[a * 3] * z0 + X[a * 3 + 1] * z1 + X[a * 3 + 2] * z2;   // nu += (H K) ze
-                }
-            } else {
+                for (int j = 0; j < 3; j++)
+                    A[i * 3 + j] = fma(-F[i * 3 + 2], Y[6 + j], fma(-F[i * 3 + 1], Y[3 + j], fma(-F[i * 3], Y[j], A[i * 3 + j])));
+            if (bj == ib && bi > ib) {
+                const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
 #pragma unroll
-                for (int k = 0; k < 9; k++) A[k] -= X[k];
+                for (int a = 0; a < 3; a++) sNu[3 * bi + a] -= A[a * 3] * z0 + A[a * 3 + 1] * z1 + A[a * 3 + 2] * z2;   // nu += (H K) ze, H K = -A
             }
             if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[k]; }
             if (bi == ib + 1 && bj == ib + 1) {                  // next pivot block S_{ib+1}: invert it now

@@ -28,6 +28,9 @@
 #define __device__
 #define __host__
 #define __shared__ static thread_local
+#ifndef __align__
+#define __align__(n) __attribute__((aligned(n)))
+#endif
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
@@ -92,6 +95,12 @@ inline void __syncthreads() {
 }
 inline void __threadfence() { __sync_synchronize(); }
 inline void __threadfence_block() { __sync_synchronize(); }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T, class U> inline void __hip_atomic_store(T* p, U v, int, int) { __atomic_store_n(p, (T)v, __ATOMIC_SEQ_CST); }
+template <class T> inline T __hip_atomic_load(const T* p, int, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }
+inline unsigned long long wall_clock64() { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10; }
+inline unsigned long long clock64() { return wall_clock64() * 24; }
 
 namespace hipemu {
 template <class T> inline unsigned long long to_bits(T v) { unsigned long long b = 0; std::memcpy(&b, &v, sizeof(T)); return b; }
