@@ -37,6 +37,7 @@ class AslamInit(C.Structure):
         ("cap_starts_per_frame", C.c_uint),
         ("cap_contours_per_frame", C.c_uint),
         ("cap_points_per_frame", C.c_uint),
+        ("ekf_reserved_cus_per_xcd", C.c_int),
     ]
 
 

@@ -29,6 +29,8 @@ struct ProfSpan { int id; hipEvent_t a, b; hipStream_t st; };
 struct aslam_ctx {
     aslam_init init{};
     hipStream_t stream = nullptr;         // detection + pose (batched over frames)
+    hipStream_t stream_part = nullptr;    // detection beside an EKF chain: CU-masked so that part of every XCD stays free for the chain
+    hipStream_t last_detect = nullptr;    // stream of the most recent detection (ordering when it changes)
     hipStream_t stream_ekf = nullptr;     // EKF chain (sequential over frames); overlaps the next batch's detection
     hipEvent_t ev_detect = nullptr, ev_ekf = nullptr;
     int ekf_first = 0, ekf_count = 0;     // slots the in-flight EKF chain still reads
@@ -190,10 +192,12 @@ int check_slot_range(aslam_ctx* c, int first, int count) {
 }
 
 // detection + pose for `count` staged frames starting at slot `first` (asynchronous on the stream)
-int run_detect(aslam_ctx* c, int first, int count) {
+int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false) {
     if (c->rows == 0) return fail(c, ASLAM_E_STATE, "no frames staged");
     if (!c->have_cam) return fail(c, ASLAM_E_STATE, "camera parameters not set (aslam_set_camera)");
-    hipStream_t st = c->stream;
+    hipStream_t st = (beside_ekf && c->stream_part) ? c->stream_part : c->stream;
+    if (c->last_detect && c->last_detect != st) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_detect, 0));   // slots / work lists are shared
+    c->last_detect = st;
     const DetectCfg& g = c->cfg;
     const size_t frame_px = (size_t)g.rows * g.cols;
     const bool alias_gray = c->channels == 1;              // staged gray frames are tight: the detector reads them in place
@@ -291,6 +295,7 @@ int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool 
 
 int sync_streams(aslam_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->stream_part) HIP_TRY(c, hipStreamSynchronize(c->stream_part));
     HIP_TRY(c, hipStreamSynchronize(c->stream_ekf));
     c->ekf_count = 0;
     return ASLAM_OK;
@@ -328,6 +333,7 @@ void aslam_default_init(aslam_init* i) {
     i->max_rows = 720; i->max_cols = 1280;
     i->max_batch = 1;
     i->persistent_waves = 0;
+    i->ekf_reserved_cus_per_xcd = 0;
     i->max_updates_per_frame = 24;
     i->cap_starts_per_frame = 0; i->cap_contours_per_frame = 0; i->cap_points_per_frame = 0;
 }
@@ -360,6 +366,16 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // the latency-bound EKF chain outranks the batched detection
     bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo) == hipSuccess;
     ok = ok && hipStreamCreateWithPriority(&c->stream_ekf, hipStreamNonBlocking, prio_hi) == hipSuccess;
+    {
+        // Detection that runs beside an EKF chain is confined to part of every XCD (CU-masked stream), so that the chain's
+        // small dependent kernels always find idle CUs; mask bit i is CU i/8 of XCD i%8 (256 CUs = 8 XCDs x 32).
+        const int res = init->ekf_reserved_cus_per_xcd == 0 ? 16 : init->ekf_reserved_cus_per_xcd;
+        if (res > 0 && res < 32) {
+            uint32_t mask[8];
+            for (int w = 0; w < 8; w++) { mask[w] = 0; for (int b = 0; b < 32; b++) if ((w * 32 + b) / 8 >= res) mask[w] |= 1u << b; }
+            if (hipExtStreamCreateWithCUMask(&c->stream_part, 8, mask) != hipSuccess) { c->stream_part = nullptr; (void)hipGetLastError(); }
+        }
+    }
     ok = ok && hipEventCreateWithFlags(&c->ev_detect, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_ekf, hipEventDisableTiming) == hipSuccess;
     ok = ok && dalloc(&c->d_in, px * 3 * B) == hipSuccess;
@@ -405,6 +421,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
 void aslam_destroy(aslam_ctx* c) {
     if (!c) return;
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream_part) hipStreamSynchronize(c->stream_part);
     if (c->stream_ekf) hipStreamSynchronize(c->stream_ekf);
     prof_collect(c);
     hipFree(c->d_in); hipFree(c->d_gray); hipFree(c->d_nbr); hipFree(c->d_starts); hipFree(c->d_ctr);
@@ -416,6 +433,7 @@ void aslam_destroy(aslam_ctx* c) {
     if (c->ev_detect) hipEventDestroy(c->ev_detect);
     if (c->ev_ekf) hipEventDestroy(c->ev_ekf);
     if (c->stream) hipStreamDestroy(c->stream);
+    if (c->stream_part) hipStreamDestroy(c->stream_part);
     if (c->stream_ekf) hipStreamDestroy(c->stream_ekf);
     delete c;
 }
@@ -467,9 +485,11 @@ int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
     int r = check_slot_range(c, first, count);
     if (r) return r;
     if (with_ekf != 2) {                       // 2 = EKF only, on observations already present in the slots (tests)
-        r = run_detect(c, first, count);
+        r = run_detect(c, first, count, with_ekf == 1);
         if (r) return r;
     } else {
+        if (c->last_detect && c->last_detect != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_detect, 0));
+        c->last_detect = c->stream;
         HIP_TRY(c, hipEventRecord(c->ev_detect, c->stream));
     }
     if (with_ekf) {

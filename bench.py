@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=195, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-ekf", action="store_true", help="detect + pose only (BASELINE config 5 style)")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts of the work-queue kernels (0 = library default)")
+    ap.add_argument("--reserve", type=int, default=0, help="CUs per XCD kept free of detection beside the EKF chain (0 = library default 16, <0 = off)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -55,7 +56,7 @@ def main():
     lap = world_scene.lap_length()
     B = min(args.batch, lap)
     ctx = capi.Context(device_id=local_rank, max_rows=cfg.rows, max_cols=cfg.cols, max_batch=lap,
-                       max_landmarks=world_scene.L + 8, persistent_waves=args.waves,
+                       max_landmarks=world_scene.L + 8, persistent_waves=args.waves, ekf_reserved_cus_per_xcd=args.reserve,
                        max_updates_per_frame=24 if world_scene.M <= 24 else 64)
     D = np.zeros(5)
     ctx.set_camera(world_scene.K, D)

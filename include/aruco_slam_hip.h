@@ -54,6 +54,8 @@ typedef struct {
     unsigned cap_starts_per_frame;       /* 0 = defaults */
     unsigned cap_contours_per_frame;
     unsigned cap_points_per_frame;
+    int    ekf_reserved_cus_per_xcd;     /* CUs of every XCD (32 each) kept free of batched detection while an EKF chain runs
+                                            beside it (CU-masked detection stream); 0 = default (16), negative = no masking */
 } aslam_init;
 
 /* fills *init with the reference's shipped parameters.yaml values and sane capacities */
