@@ -353,7 +353,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     if (c->init.cap_contours_per_frame == 0) c->init.cap_contours_per_frame = 1u << 12;
     if (c->init.cap_points_per_frame == 0) c->init.cap_points_per_frame = 1u << 19;
     c->max_batch = init->max_batch;
-    c->nwaves = init->persistent_waves > 0 ? init->persistent_waves : 2048;
+    c->nwaves = init->persistent_waves > 0 ? init->persistent_waves : 4096;
     c->sp.Q_k = init->Q_k; c->sp.R_x = init->R_x; c->sp.R_y = init->R_y; c->sp.R_theta = init->R_theta;
     c->sp.kl = init->kl; c->sp.kr = init->kr; c->sp.b = init->b; c->sp.marker_length = init->marker_length;
     c->sp.r2c_tx = init->r2c_t[0]; c->sp.r2c_ty = init->r2c_t[1];
@@ -801,6 +801,9 @@ int aslam_debug_inject_observations(aslam_ctx* c, int slot, int n, const int* id
     return ASLAM_OK;
 }
 
+int aslam_debug_get_counters(aslam_ctx* c, unsigned* out) {
+    return hipMemcpy(out, c->d_ctr, 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
 int aslam_profile_enable(aslam_ctx* c, int on) { if (!c) return ASLAM_E_INVALID; c->prof_on = on != 0; return ASLAM_OK; }
 int aslam_profile_reset(aslam_ctx* c) {
     if (!c) return ASLAM_E_INVALID;

@@ -266,6 +266,37 @@ __device__ __forceinline__ void walk_step(Walk& w, unsigned m) {
 }
 
 constexpr int kTraceChunk = 256;
+constexpr int kRunLook = 8;          // pixels of the start candidate's run examined by the two tests below
+
+// A border's canonical start (the state the sequential raster scan starts it from) lies on the FIRST row of the border /
+// hole, so nothing of the same component may sit above the horizontal run it opens.  k_threshold's candidate test only
+// looks at the first pixel of that run; these look kRunLook pixels further (or to the run's end).  They are necessary
+// conditions of being canonical, applied identically when a candidate is picked up and when a walk asks whether it has
+// reached another candidate, so they only discard walks that could never have emitted a contour (e.g. one per stair
+// step of a slanted edge).
+//   outer: foreground run starting at (x, y) whose first pixel has W/NW/N/NE background: no later pixel of the run
+//          may have a N or NE foreground neighbour.
+//   hole : background run starting at (x, y) (W and N foreground): every pixel of the run must have N foreground (the
+//          background is 4-connected), and the run must end inside the image.
+__device__ __forceinline__ bool run_is_top_outer(const uint8_t* __restrict__ plane, int x, int y, int pitch, unsigned m0) {
+    unsigned m = m0;
+    for (int t = 1; t <= kRunLook; t++) {
+        if (!(m & 1u)) return true;                        // run ended (E is background)
+        m = plane[nbr_index(x + t, y, pitch)];
+        if (m & 0x06u) return false;                       // something above this run pixel
+    }
+    return true;
+}
+__device__ __forceinline__ bool run_is_top_hole(const uint8_t* __restrict__ plane, int x, int y, int pitch, int cols) {
+    unsigned m = plane[nbr_index(x, y, pitch)];            // the hole pixel itself (background, W and N foreground)
+    for (int t = 1; t <= kRunLook; t++) {
+        if (m & 1u) return true;                           // run ended (E is foreground)
+        if (x + t >= cols) return false;                   // open to the image frame: not a hole
+        m = plane[nbr_index(x + t, y, pitch)];
+        if (!(m & 0x04u)) return false;                    // the background continues upwards
+    }
+    return true;
+}
 
 // Work-queue kernel.  Every lane is a small state machine (idle -> validate walk -> write walk -> idle); idle lanes are
 // refilled from the queue every iteration with ONE atomic per wave, so a wave never waits for its longest walk.
@@ -288,9 +319,11 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
     const uint8_t* plane = nbr;
     Walk w{0, 0, 0};
     int sx = 0, sy = 0, s0 = 0, key0 = 0, n = 0, wi = 0, f = 0;
+    int kmin_outer = INT_MAX, kmin_hole = INT_MAX;
     unsigned type = 0, sc = 0;
     long long area = 0;
     unsigned* dst = points;
+    unsigned dbg_iters = 0, dbg_steps = 0, dbg_w = 0;
 
     for (;;) {
         // ---- refill idle lanes from the wave's private ticket range; a new range costs one atomic per kTraceChunk tickets ----
@@ -315,26 +348,43 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                 type = (e >> 26) & 1u;
                 plane = nbr + ((size_t)f * kScales + sc) * nbr_plane_bytes(cfg.rows, pitch);
                 key0 = y * cols + x;
-                if (type) x -= 1;                                  // hole border starts on the pixel left of the hole
-                const unsigned m0 = plane[nbr_index(x, y, pitch)];
-                s0 = type ? first_hole(m0) : first_outer(m0);
-                sx = x; sy = y;
-                w = Walk{sx, sy, s0};
-                area = 0;
-                n = 0;
-                mode = 1;
+                const bool top = type ? run_is_top_hole(plane, x, y, pitch, cols)
+                                      : run_is_top_outer(plane, x, y, pitch, plane[nbr_index(x, y, pitch)]);
+                if (top) {
+                    if (type) x -= 1;                              // hole border starts on the pixel left of the hole
+                    const unsigned m0 = plane[nbr_index(x, y, pitch)];
+                    s0 = type ? first_hole(m0) : first_outer(m0);
+                    sx = x; sy = y;
+                    w = Walk{sx, sy, s0};
+                    area = 0;
+                    n = 0;
+                    kmin_outer = type ? INT_MAX : key0;
+                    kmin_hole = type ? key0 : INT_MAX;
+                    mode = 1;
+                }
             }
             lo += take;
         }
-        if (__ballot(mode != 0) == 0ull) break;
+        if (__ballot(mode != 0) == 0ull) {
+            if (drained) break;
+            continue;                                              // every candidate just picked up was discarded: fetch more
+        }
+        dbg_iters++; dbg_steps += (unsigned)__popcll(__ballot(mode != 0)); dbg_w += (unsigned)__popcll(__ballot(mode == 2));
 
         // ---- one step per busy lane ----
         if (mode == 1) {
             const unsigned m = plane[nbr_index(w.x, w.y, pitch)];
             bool dead = false;
-            // is this state the start state of another scan candidate of my type with a smaller key?
-            if (type == 0) dead = (m & 0x1Eu) == 0 && w.s == first_outer(m) && w.y * cols + w.x < key0;
-            else dead = (m & 3u) == 2u && w.s == first_hole(m) && w.y * cols + w.x + 1 < key0;
+            // Is this state the start state of a scan candidate (of either type)?  A smaller key that passes the run test
+            // belongs to a walker that will do (or hand on) this border: stop.  Otherwise remember the smallest key per
+            // type: whoever closes the border needs the first start of the border's own type (outer / hole).
+            const bool co = (m & 0x1Eu) == 0 && w.s == first_outer(m);
+            const bool ch = (m & 3u) == 2u && w.s == first_hole(m);
+            if (co || ch) {
+                const int key = w.y * cols + w.x + (ch ? 1 : 0);
+                if (key < key0) dead = ch ? run_is_top_hole(plane, w.x + 1, w.y, pitch, cols) : run_is_top_outer(plane, w.x, w.y, pitch, m);
+                if (ch) kmin_hole = min(kmin_hole, key); else kmin_outer = min(kmin_outer, key);
+            }
             if (dead) {
                 mode = 0;
             } else {
@@ -343,20 +393,26 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                 area += (long long)px * w.y - (long long)w.x * py;
                 n++;
                 if (w.x == sx && w.y == sy && w.s == s0) {
-                    // closed: keep it only if this was the start the sequential scan would have used
+                    // closed by the smallest surviving key on this border: emit it from the start the sequential scan would
+                    // have used = the first candidate of the border's own type
                     const bool is_hole = area > 0;                 // outer borders run counter-clockwise on screen
-                    bool keep = ((unsigned)is_hole == type) && n >= cfg.min_perim && n <= cfg.max_perim;
+                    const int ckey = is_hole ? kmin_hole : kmin_outer;
+                    const bool keep = ckey != INT_MAX && n >= cfg.min_perim && n <= cfg.max_perim;
                     mode = 0;
                     if (keep) {
+                        sx = ckey % cols - (is_hole ? 1 : 0);
+                        sy = ckey / cols;
+                        const unsigned mc = plane[nbr_index(sx, sy, pitch)];
+                        s0 = is_hole ? first_hole(mc) : first_outer(mc);
                         const unsigned ci = atomicAdd(&n_contours[f], 1u);
                         const unsigned off = atomicAdd(&n_points[f], (unsigned)n);
                         if (ci >= cfg.cap_contours) {
                             atomicOr(&ctr->overflow, (unsigned)kOvfContours);
                         } else if ((unsigned long long)off + (unsigned)n > cfg.cap_points) {
                             atomicOr(&ctr->overflow, (unsigned)kOvfPoints);
-                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)key0, 0u, 0u, (short)sx, (short)sy, s0};
+                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, 0u, 0u, (short)sx, (short)sy, s0};
                         } else {
-                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)key0, (unsigned)n, off, (short)sx, (short)sy, s0};
+                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, (unsigned)n, off, (short)sx, (short)sy, s0};
                             dst = points + (size_t)f * cfg.cap_points + off;
                             w = Walk{sx, sy, s0};
                             wi = 0;
@@ -374,6 +430,7 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
             if (++wi >= n) mode = 0;
         }
     }
+    if (lane == 0) { atomicAdd(&ctr->pad[0], dbg_iters); atomicAdd(&ctr->pad[1], dbg_steps >> 4); atomicAdd(&ctr->pad[2], dbg_w >> 4); }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -47,7 +47,7 @@ typedef struct {
     int    max_landmarks;                /* capacity of the EKF state: N_max = 3 + 3*max_landmarks */
     int    max_rows, max_cols;           /* largest frame that will be handed over */
     int    max_batch;                    /* frames staged / processed per call of the *_staged functions */
-    int    persistent_waves;             /* wavefronts of the work-queue kernels; 0 = default (2048) */
+    int    persistent_waves;             /* wavefronts of the work-queue kernels; 0 = default (4096) */
     int    max_updates_per_frame;        /* EKF corrections fused per frame; <= 24 selects the 3-kernel fast chain,
                                             larger values (up to 128) the general 5-kernel chain; exceeding it at run
                                             time is reported as ASLAM_E_CAPACITY */

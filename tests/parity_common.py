@@ -85,6 +85,10 @@ def run_slam_sequence(cfg, n_frames, batch, literal, noise_amp=2, per_frame_chec
                 t_now += frs[i].dt
                 o.add_encoder(frs[i].wl, frs[i].wr, t_now)
                 o.add_image(imgs[i])
+                d_ids, d_c = o.log_detections()[:2]
+                g_ids, g_c = ctx.get_slot_detections(i)[:2]
+                assert np.array_equal(d_ids, g_ids), f"frame {f0 + i}: marker ids differ"
+                assert np.array_equal(d_c, g_c), f"frame {f0 + i}: marker corners differ"
             oi, ox, oa, oz, oR = o.log_observations()
             gi, gx, ga, gz, gR = ctx.get_observations()
             assert np.array_equal(oi, gi), "pop order (ids) differs"

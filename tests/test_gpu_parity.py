@@ -109,6 +109,15 @@ def test_slam_sequence_cfg2_headline():
     assert (np.diag(S) > 0).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", [256, 4096, 8192])
+def test_results_do_not_depend_on_the_number_of_work_queue_waves(waves):
+    """the work-queue kernels (k_trace, k_quads, k_identify) hand out work dynamically: any wave count gives the same frames"""
+    cfg = synth.CONFIGS["cfg2"]
+    stats, ctx, o = pc.run_slam_sequence(cfg, 48, batch=24, literal=False, ctx_kwargs=dict(persistent_waves=waves))
+    assert stats["max_sigma"] < pc.TIGHT
+
+
 def test_single_frame_api_matches_staged_api():
     """aslam_add_encoder / aslam_add_image (the ArucoSlam::addEncoder / addImage surface) == staged stream API"""
     cfg = synth.CONFIGS["cfg1"]
