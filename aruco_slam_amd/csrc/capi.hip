@@ -55,6 +55,10 @@ struct aslam_ctx {
     unsigned* d_ncontours = nullptr;
     unsigned* d_points = nullptr;          // per frame: cap_points packed (x, y)
     unsigned* d_npoints = nullptr;
+    CkptRec* d_ckpt = nullptr;             // per frame: cap_ckpt walk checkpoints of the kept contours
+    unsigned* d_nckpt = nullptr;
+    unsigned* d_lane_ckpt = nullptr;       // k_trace: checkpoints of the walk each lane has in progress
+    unsigned* d_pre_write = nullptr;
     unsigned* d_pre_trace = nullptr;       // ticket ranges of the work-queue kernels
     unsigned* d_pre_quads = nullptr;
     CandRec* d_cands = nullptr;
@@ -183,6 +187,8 @@ int configure_frames(aslam_ctx* c, int rows, int cols, int channels) {
     g.cap_starts = c->init.cap_starts_per_frame;
     g.cap_contours = c->init.cap_contours_per_frame;
     g.cap_points = c->init.cap_points_per_frame;
+    g.cap_ckpt = g.cap_points / kCkptStride + g.cap_contours;
+    g.ckpt_per_walk = g.max_perim / kCkptStride + 2;      // <= the per-lane allocation sized from max_rows / max_cols
     return ASLAM_OK;
 }
 
@@ -209,10 +215,11 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false) {
     }
     for (int f0 = first; f0 < first + count; f0 += max_frames_per_call()) {
         const int nf = std::min(max_frames_per_call(), first + count - f0);
-        HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, 4 * sizeof(unsigned), st));       // queue heads and work count; the overflow mask is sticky
+        HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, kCounterHeads * sizeof(unsigned), st));   // queue heads and work count; the overflow mask is sticky
         HIP_TRY(c, hipMemsetAsync(c->d_nstarts + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_ncontours + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_npoints + f0, 0, sizeof(unsigned) * nf, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_nckpt + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_ncand + f0, 0, sizeof(unsigned) * nf, st));
         const uint8_t* in = c->d_in + (size_t)f0 * c->in_frame_bytes;
         uint8_t* nbr = c->d_nbr + (size_t)f0 * kScales * nbr_plane_bytes(g.rows, g.pitch);
@@ -226,8 +233,11 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false) {
         prof_end(c);
         prof_begin(c, P_TRACE, st);
         launch_prefix(st, nf, c->d_nstarts + f0, g.cap_starts, 1u, c->d_pre_trace);
+        CkptRec* ckpt = c->d_ckpt + (size_t)f0 * g.cap_ckpt;
         launch_trace(st, c->nwaves, nbr, g, nf, starts, c->d_nstarts + f0, c->d_pre_trace, c->d_ctr, contours, c->d_ncontours + f0,
-                     points, c->d_npoints + f0);
+                     c->d_npoints + f0, ckpt, c->d_nckpt + f0, c->d_lane_ckpt);
+        launch_prefix(st, nf, c->d_nckpt + f0, g.cap_ckpt, 1u, c->d_pre_write);
+        launch_trace_write(st, std::max(64, c->nwaves / 4), nbr, g, nf, c->d_pre_write, c->d_ctr, contours, ckpt, points);
         prof_end(c);
         prof_begin(c, P_QUADS, st);
         launch_prefix(st, nf, c->d_ncontours + f0, g.cap_contours, 1u, c->d_pre_quads);
@@ -388,6 +398,10 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && dalloc(&c->d_ncontours, B) == hipSuccess;
     ok = ok && dalloc(&c->d_points, (size_t)c->init.cap_points_per_frame * B) == hipSuccess;
     ok = ok && dalloc(&c->d_npoints, B) == hipSuccess;
+    ok = ok && dalloc(&c->d_ckpt, ((size_t)c->init.cap_points_per_frame / kCkptStride + c->init.cap_contours_per_frame) * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_nckpt, B) == hipSuccess;
+    ok = ok && dalloc(&c->d_lane_ckpt, (size_t)c->nwaves * 64 * ((size_t)(4.0 * std::max(init->max_rows, init->max_cols)) / kCkptStride + 2)) == hipSuccess;
+    ok = ok && dalloc(&c->d_pre_write, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_trace, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_quads, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_cands, (size_t)kCandMax * B) == hipSuccess;
@@ -425,6 +439,7 @@ void aslam_destroy(aslam_ctx* c) {
     if (c->stream_ekf) hipStreamSynchronize(c->stream_ekf);
     prof_collect(c);
     hipFree(c->d_in); hipFree(c->d_gray); hipFree(c->d_nbr); hipFree(c->d_starts); hipFree(c->d_ctr);
+    hipFree(c->d_ckpt); hipFree(c->d_nckpt); hipFree(c->d_lane_ckpt); hipFree(c->d_pre_write);
     hipFree(c->d_nstarts); hipFree(c->d_ncontours); hipFree(c->d_npoints); hipFree(c->d_pre_trace); hipFree(c->d_pre_quads);
     hipFree(c->d_contours); hipFree(c->d_points); hipFree(c->d_cands); hipFree(c->d_ncand); hipFree(c->d_finals);
     hipFree(c->d_nfinal); hipFree(c->d_work); hipFree(c->d_dict); hipFree(c->d_markers); hipFree(c->d_nmarkers);

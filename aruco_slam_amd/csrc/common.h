@@ -36,17 +36,26 @@ struct DetectCfg {
     int max_corr;                     // int(maxCorrectionBits * errorCorrectionRate)
     int n_dict;                       // markers in the dictionary
     double min_otsu_std;              // 5.0
-    unsigned cap_starts, cap_contours, cap_points;   // per frame
+    unsigned cap_starts, cap_contours, cap_points, cap_ckpt;   // per frame
+    int ckpt_per_walk;                // checkpoints one border walk can leave: max_perim / kCkptStride + 2
 };
 
 struct Counters {                 // per-call scalars (work-queue heads, overflow mask); list sizes live in per-frame arrays
-    unsigned q_trace, q_quads, n_ident, q_ident, overflow, pad[3];
+    unsigned q_trace, q_quads, n_ident, q_ident, q_write, overflow, pad[2];
 };
+constexpr int kCounterHeads = 5;  // leading words reset before every detection call (the overflow mask is sticky)
 
 struct ContourRec {
     unsigned frame, scale, key, n, off;
-    short sx, sy;
+    short sx, sy;                 // the start state the sequential scan would have used (point 0 of the contour)
     int s0;
+    unsigned ck_off;              // first of its ceil(n / kCkptStride) checkpoints in the frame's checkpoint list
+    int kpos;                     // step of the closing walk at which it stood on (sx, sy, s0): point i = walk step kpos + i (mod n)
+};
+
+constexpr int kCkptStride = 64;   // border-walk steps between two checkpoints (= steps one lane of k_trace_write replays)
+struct CkptRec {                  // walk state every kCkptStride steps of a kept contour: x[0:12) y[12:24) s[24:27), and its contour
+    unsigned state, ci;
 };
 
 struct CandRec {                  // quad that passed _findMarkerContours

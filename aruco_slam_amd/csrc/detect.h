@@ -9,7 +9,9 @@ void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t fr
 void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre);
 void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
                   const unsigned* n_starts, const unsigned* pre, Counters* ctr, ContourRec* contours, unsigned* n_contours,
-                  unsigned* points, unsigned* n_points);
+                  unsigned* n_points, CkptRec* ckpt, unsigned* n_ckpt, unsigned* lane_ckpt);
+void launch_trace_write(hipStream_t st, int nblocks, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* pre,
+                        Counters* ctr, const ContourRec* contours, const CkptRec* ckpt, unsigned* points);
 void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, int nframes, Counters* ctr, const ContourRec* contours,
                   const unsigned* n_contours, const unsigned* pre, const unsigned* points, CandRec* cands, unsigned* n_cand);
 void launch_assemble(hipStream_t st, int nframes, const DetectCfg& cfg, Counters* ctr, const CandRec* cands,

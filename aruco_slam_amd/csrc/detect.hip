@@ -305,7 +305,8 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                                               const unsigned* __restrict__ starts, const unsigned* __restrict__ n_starts,
                                               const unsigned* __restrict__ pre, Counters* ctr,
                                               ContourRec* __restrict__ contours, unsigned* __restrict__ n_contours,
-                                              unsigned* __restrict__ points, unsigned* __restrict__ n_points) {
+                                              unsigned* __restrict__ n_points, CkptRec* __restrict__ ckpt,
+                                              unsigned* __restrict__ n_ckpt, unsigned* __restrict__ lane_ckpt) {
     __shared__ unsigned sPre[kMaxFramesPerCall + 1];
     const int lane = threadIdx.x & 63;
     for (int i = lane; i <= nframes; i += 64) sPre[i] = pre[i];
@@ -313,17 +314,18 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
     const unsigned total = sPre[nframes];
     const int pitch = cfg.pitch, cols = cfg.cols;
 
-    int mode = 0;                       // 0 idle, 1 validate, 2 write
+    int mode = 0;                       // 0 idle, 1 walk, 2 hand the checkpoints of a kept contour over
     bool drained = false;               // the queue is empty (wave-uniform)
     unsigned lo = 0, hi = 0;            // the wave's private ticket range (wave-uniform)
     const uint8_t* plane = nbr;
     Walk w{0, 0, 0};
     int sx = 0, sy = 0, s0 = 0, key0 = 0, n = 0, wi = 0, f = 0;
-    int kmin_outer = INT_MAX, kmin_hole = INT_MAX;
+    int kmin_outer = INT_MAX, kmin_hole = INT_MAX, kpos_outer = 0, kpos_hole = 0;
+    unsigned* myck = lane_ckpt + ((size_t)blockIdx.x * 64 + lane) * cfg.ckpt_per_walk;   // this lane's checkpoints of the walk in progress
+    CkptRec* ckdst = ckpt;
+    unsigned ci_keep = 0;
     unsigned type = 0, sc = 0;
     long long area = 0;
-    unsigned* dst = points;
-    unsigned dbg_iters = 0, dbg_steps = 0, dbg_w = 0;
 
     for (;;) {
         // ---- refill idle lanes from the wave's private ticket range; a new range costs one atomic per kTraceChunk tickets ----
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                     n = 0;
                     kmin_outer = type ? INT_MAX : key0;
                     kmin_hole = type ? key0 : INT_MAX;
+                    kpos_outer = kpos_hole = 0;
                     mode = 1;
                 }
             }
@@ -369,7 +372,6 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
             if (drained) break;
             continue;                                              // every candidate just picked up was discarded: fetch more
         }
-        dbg_iters++; dbg_steps += (unsigned)__popcll(__ballot(mode != 0)); dbg_w += (unsigned)__popcll(__ballot(mode == 2));
 
         // ---- one step per busy lane ----
         if (mode == 1) {
@@ -383,11 +385,13 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
             if (co || ch) {
                 const int key = w.y * cols + w.x + (ch ? 1 : 0);
                 if (key < key0) dead = ch ? run_is_top_hole(plane, w.x + 1, w.y, pitch, cols) : run_is_top_outer(plane, w.x, w.y, pitch, m);
-                if (ch) kmin_hole = min(kmin_hole, key); else kmin_outer = min(kmin_outer, key);
+                if (ch) { if (key < kmin_hole) { kmin_hole = key; kpos_hole = n; } }
+                else if (key < kmin_outer) { kmin_outer = key; kpos_outer = n; }
             }
             if (dead) {
                 mode = 0;
             } else {
+                if ((n & (kCkptStride - 1)) == 0) myck[n / kCkptStride] = (unsigned)w.x | ((unsigned)w.y << 12) | ((unsigned)w.s << 24);
                 const int px = w.x, py = w.y;
                 walk_step(w, m);
                 area += (long long)px * w.y - (long long)w.x * py;
@@ -400,22 +404,25 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                     const bool keep = ckey != INT_MAX && n >= cfg.min_perim && n <= cfg.max_perim;
                     mode = 0;
                     if (keep) {
-                        sx = ckey % cols - (is_hole ? 1 : 0);
-                        sy = ckey / cols;
-                        const unsigned mc = plane[nbr_index(sx, sy, pitch)];
-                        s0 = is_hole ? first_hole(mc) : first_outer(mc);
+                        const int cx = ckey % cols - (is_hole ? 1 : 0), cy = ckey / cols;
+                        const unsigned mc = plane[nbr_index(cx, cy, pitch)];
+                        const int cs = is_hole ? first_hole(mc) : first_outer(mc);
+                        const unsigned ncp = ((unsigned)n + kCkptStride - 1) / kCkptStride;
                         const unsigned ci = atomicAdd(&n_contours[f], 1u);
                         const unsigned off = atomicAdd(&n_points[f], (unsigned)n);
+                        const unsigned cko = atomicAdd(&n_ckpt[f], ncp);
                         if (ci >= cfg.cap_contours) {
                             atomicOr(&ctr->overflow, (unsigned)kOvfContours);
-                        } else if ((unsigned long long)off + (unsigned)n > cfg.cap_points) {
+                        } else if ((unsigned long long)off + (unsigned)n > cfg.cap_points || (unsigned long long)cko + ncp > cfg.cap_ckpt) {
                             atomicOr(&ctr->overflow, (unsigned)kOvfPoints);
-                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, 0u, 0u, (short)sx, (short)sy, s0};
+                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, 0u, 0u, (short)cx, (short)cy, cs, 0u, 0};
                         } else {
-                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, (unsigned)n, off, (short)sx, (short)sy, s0};
-                            dst = points + (size_t)f * cfg.cap_points + off;
-                            w = Walk{sx, sy, s0};
+                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, (unsigned)n, off, (short)cx, (short)cy, cs,
+                                                                                    cko, is_hole ? kpos_hole : kpos_outer};
+                            ckdst = ckpt + (size_t)f * cfg.cap_ckpt + cko;
+                            ci_keep = ci;
                             wi = 0;
+                            n = (int)ncp;
                             mode = 2;
                         }
                     }
@@ -424,13 +431,53 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                 }
             }
         } else if (mode == 2) {
-            dst[wi] = ((unsigned)w.x & 0xFFFFu) | ((unsigned)w.y << 16);
-            const unsigned m = plane[nbr_index(w.x, w.y, pitch)];
-            walk_step(w, m);
+            ckdst[wi] = CkptRec{myck[wi], ci_keep};           // one checkpoint per iteration (at most cfg.ckpt_per_walk)
             if (++wi >= n) mode = 0;
         }
     }
-    if (lane == 0) { atomicAdd(&ctr->pad[0], dbg_iters); atomicAdd(&ctr->pad[1], dbg_steps >> 4); atomicAdd(&ctr->pad[2], dbg_w >> 4); }
+}
+
+// k_trace_write: the points of every kept contour, kCkptStride of them per lane: replay the border walk from a checkpoint.
+// Tickets number the checkpoints of the whole call (`pre` = per-frame prefix of their counts); point i of a contour is the
+// state at step kpos + i of the closing walk, so step j of that walk lands at index (j - kpos) mod n.
+__global__ __launch_bounds__(256) void k_trace_write(const uint8_t* __restrict__ nbr, DetectCfg cfg, int nframes,
+                                                     const unsigned* __restrict__ pre, Counters* ctr,
+                                                     const ContourRec* __restrict__ contours, const CkptRec* __restrict__ ckpt,
+                                                     unsigned* __restrict__ points) {
+    __shared__ unsigned sPre[kMaxFramesPerCall + 1];
+    __shared__ unsigned sBase;
+    const int tid = threadIdx.x;
+    for (int i = tid; i <= nframes; i += 256) sPre[i] = pre[i];
+    __syncthreads();
+    const unsigned total = sPre[nframes];
+    const int pitch = cfg.pitch;
+    for (;;) {
+        if (tid == 0) sBase = atomicAdd(&ctr->q_write, 256u);
+        __syncthreads();
+        const unsigned base = sBase;
+        __syncthreads();
+        if (base >= total) break;                              // uniform
+        const unsigned ticket = base + tid;
+        if (ticket < total) {
+            const int f = ticket_frame(sPre, nframes, ticket);
+            const unsigned q = ticket - sPre[f];
+            const CkptRec ck = ckpt[(size_t)f * cfg.cap_ckpt + q];
+            const ContourRec rec = contours[(size_t)f * cfg.cap_contours + ck.ci];
+            const uint8_t* plane = nbr + ((size_t)f * kScales + rec.scale) * nbr_plane_bytes(cfg.rows, pitch);
+            unsigned* dst = points + (size_t)f * cfg.cap_points + rec.off;
+            const int n = (int)rec.n;
+            int j = (int)(q - rec.ck_off) * kCkptStride;       // first walk step of this segment
+            const int jend = min(j + kCkptStride, n);
+            int idx = j - rec.kpos;
+            if (idx < 0) idx += n;
+            Walk w{(int)(ck.state & 0xFFFu), (int)((ck.state >> 12) & 0xFFFu), (int)((ck.state >> 24) & 7u)};
+            for (; j < jend; j++) {
+                dst[idx] = ((unsigned)w.x & 0xFFFFu) | ((unsigned)w.y << 16);
+                walk_step(w, plane[nbr_index(w.x, w.y, pitch)]);
+                if (++idx >= n) idx = 0;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -956,9 +1003,13 @@ void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned
 }
 void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
                   const unsigned* n_starts, const unsigned* pre, Counters* ctr, ContourRec* contours, unsigned* n_contours,
-                  unsigned* points, unsigned* n_points) {
+                  unsigned* n_points, CkptRec* ckpt, unsigned* n_ckpt, unsigned* lane_ckpt) {
     hipLaunchKernelGGL(k_trace, dim3(nwaves), dim3(64), 0, st, nbr, cfg, nframes, starts, n_starts, pre, ctr, contours, n_contours,
-                       points, n_points);
+                       n_points, ckpt, n_ckpt, lane_ckpt);
+}
+void launch_trace_write(hipStream_t st, int nblocks, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* pre,
+                        Counters* ctr, const ContourRec* contours, const CkptRec* ckpt, unsigned* points) {
+    hipLaunchKernelGGL(k_trace_write, dim3(nblocks), dim3(256), 0, st, nbr, cfg, nframes, pre, ctr, contours, ckpt, points);
 }
 void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, int nframes, Counters* ctr, const ContourRec* contours,
                   const unsigned* n_contours, const unsigned* pre, const unsigned* points, CandRec* cands, unsigned* n_cand) {
