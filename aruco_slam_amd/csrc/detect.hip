@@ -445,8 +445,9 @@ __global__ __launch_bounds__(256) void k_trace_write(const uint8_t* __restrict__
                                                      const ContourRec* __restrict__ contours, const CkptRec* __restrict__ ckpt,
                                                      unsigned* __restrict__ points) {
     __shared__ unsigned sPre[kMaxFramesPerCall + 1];
+    __shared__ unsigned sPts[4][64][64];
     __shared__ unsigned sBase;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i <= nframes; i += 256) sPre[i] = pre[i];
     __syncthreads();
     const unsigned total = sPre[nframes];
@@ -458,23 +459,39 @@ __global__ __launch_bounds__(256) void k_trace_write(const uint8_t* __restrict__
         __syncthreads();
         if (base >= total) break;                              // uniform
         const unsigned ticket = base + tid;
+        // every lane replays its segment into LDS (skewed so that the transposed read below is conflict-free) ...
+        unsigned* dst = points;
+        int n = 1, idx0 = 0, cnt = 0;
         if (ticket < total) {
             const int f = ticket_frame(sPre, nframes, ticket);
             const unsigned q = ticket - sPre[f];
             const CkptRec ck = ckpt[(size_t)f * cfg.cap_ckpt + q];
             const ContourRec rec = contours[(size_t)f * cfg.cap_contours + ck.ci];
             const uint8_t* plane = nbr + ((size_t)f * kScales + rec.scale) * nbr_plane_bytes(cfg.rows, pitch);
-            unsigned* dst = points + (size_t)f * cfg.cap_points + rec.off;
-            const int n = (int)rec.n;
-            int j = (int)(q - rec.ck_off) * kCkptStride;       // first walk step of this segment
-            const int jend = min(j + kCkptStride, n);
-            int idx = j - rec.kpos;
-            if (idx < 0) idx += n;
+            dst = points + (size_t)f * cfg.cap_points + rec.off;
+            n = (int)rec.n;
+            const int j0 = (int)(q - rec.ck_off) * kCkptStride;        // first walk step of this segment
+            cnt = min(kCkptStride, n - j0);
+            idx0 = j0 - rec.kpos;
+            if (idx0 < 0) idx0 += n;
             Walk w{(int)(ck.state & 0xFFFu), (int)((ck.state >> 12) & 0xFFFu), (int)((ck.state >> 24) & 7u)};
-            for (; j < jend; j++) {
-                dst[idx] = ((unsigned)w.x & 0xFFFFu) | ((unsigned)w.y << 16);
+            for (int t = 0; t < cnt; t++) {
+                sPts[wave][lane][(t + lane) & 63] = ((unsigned)w.x & 0xFFFFu) | ((unsigned)w.y << 16);
                 walk_step(w, plane[nbr_index(w.x, w.y, pitch)]);
-                if (++idx >= n) idx = 0;
+            }
+        }
+        // ... and the wave writes segment after segment, 64 consecutive points (256 B) per store
+        const unsigned long long dptr = (unsigned long long)dst;
+        for (int sgm = 0; sgm < 64; sgm++) {
+            const int scnt = __shfl(cnt, sgm);
+            if (scnt == 0) continue;                           // wave-uniform
+            const int sn = __shfl(n, sgm), sidx = __shfl(idx0, sgm);
+            const unsigned lo32 = __shfl((unsigned)dptr, sgm), hi32 = __shfl((unsigned)(dptr >> 32), sgm);
+            unsigned* sdst = (unsigned*)(((unsigned long long)hi32 << 32) | lo32);
+            if (lane < scnt) {
+                int o = sidx + lane;
+                if (o >= sn) o -= sn;
+                sdst[o] = sPts[wave][sgm][(lane + sgm) & 63];
             }
         }
     }
@@ -504,9 +521,10 @@ __device__ __forceinline__ void wave_first_max(double& d, int& pos) {
 // floor(count/2) of them, so new_count + stack > 8 can never end at 4.  All lanes run the same control flow.
 __device__ int approx_poly_closed_wave(const unsigned* __restrict__ src, int count, double eps, IPt* out, int lane) {
     struct Range { int start, end; };
-    Range stack[10];
+    // wave-uniform work arrays: one copy per wavefront in LDS (every lane stores the same value) instead of per-lane scratch
+    __shared__ Range stack[10];
+    __shared__ IPt dst[9];
     int top = 0;
-    IPt dst[9];
     Range slice{0, 0}, right_slice{0, 0};
     IPt start_pt{-1000000, -1000000}, end_pt{0, 0}, pt{0, 0};
     int pos = 0, new_count = 0;
@@ -637,7 +655,7 @@ __global__ __launch_bounds__(64) void k_quads(DetectCfg cfg, int nframes, Counte
         const int f = ticket_frame(sPre, nframes, ticket);
         const ContourRec rec = contours[(size_t)f * cfg.cap_contours + (ticket - sPre[f])];
         if (rec.n > 0) {                                       // wave-uniform
-            IPt q[8];
+            __shared__ IPt q[8];                                // wave-uniform, like the work arrays of approx_poly_closed_wave
             int nv = approx_poly_closed_wave(points + (size_t)f * cfg.cap_points + rec.off, (int)rec.n,
                                              (double)rec.n * cfg.approx_rate, q, lane);
             bool ok = nv == 4 && quad_is_convex(q);

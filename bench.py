@@ -158,11 +158,12 @@ def main():
     alg_bytes = per_frame_bytes[dominant] * (args.steps * B / launches if not dominant.startswith("k_ekf") else 1)
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     # HBM traffic of that kernel per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-    # runs of this same command; profiles/r01_pmc_traffic.json).  FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
+    # runs of this same command; the newest profiles/*_pmc_traffic.json, see scripts/profile_round.sh).  FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
     # (MI355X_MICROARCH.md §HBM); the figure is given uncorrected, scaled to this run's frames per launch.
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dominant)
+        import glob
+        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))["kernels"].get(dominant)
         if pmc:
             scale = 1.0 if dominant.startswith("k_ekf") else (args.steps * B / launches) / 200.0
             traffic = int((pmc.get("FETCH_SIZE_KB_per_launch", 0) + pmc.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 * scale)
