@@ -41,6 +41,28 @@ class AslamInit(C.Structure):
     ]
 
 
+class DetectorParams(C.Structure):
+    """mirror of aslam_detector_params (cv::aruco::DetectorParameters of OpenCV 3.2.0)"""
+    _fields_ = [
+        ("adaptiveThreshWinSizeMin", C.c_int), ("adaptiveThreshWinSizeMax", C.c_int), ("adaptiveThreshWinSizeStep", C.c_int),
+        ("adaptiveThreshConstant", C.c_double),
+        ("minMarkerPerimeterRate", C.c_double), ("maxMarkerPerimeterRate", C.c_double),
+        ("polygonalApproxAccuracyRate", C.c_double),
+        ("minCornerDistanceRate", C.c_double),
+        ("minDistanceToBorder", C.c_int),
+        ("minMarkerDistanceRate", C.c_double),
+        ("doCornerRefinement", C.c_int),
+        ("cornerRefinementWinSize", C.c_int), ("cornerRefinementMaxIterations", C.c_int),
+        ("cornerRefinementMinAccuracy", C.c_double),
+        ("markerBorderBits", C.c_int),
+        ("perspectiveRemovePixelPerCell", C.c_int),
+        ("perspectiveRemoveIgnoredMarginPerCell", C.c_double),
+        ("maxErroneousBitsInBorderRate", C.c_double),
+        ("minOtsuStdDev", C.c_double),
+        ("errorCorrectionRate", C.c_double),
+    ]
+
+
 class AslamError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"aslam error {code} ({E_NAMES.get(code, '?')}): {msg}")
@@ -56,6 +78,10 @@ _SIGS = {
     "aslam_destroy": (None, [C.c_void_p]),
     "aslam_last_error": (C.c_char_p, [C.c_void_p]),
     "aslam_set_camera": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int]),
+    "aslam_default_detector_params": (None, [C.c_void_p]),
+    "aslam_set_detector_params": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aslam_set_dictionary": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "aslam_set_dictionary_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "aslam_add_encoder": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "aslam_add_image": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_size_t]),
     "aslam_get_state": (C.c_int, [C.c_void_p, _ip, _dp, _dp]),
@@ -155,6 +181,26 @@ class Context:
         K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
         D = np.zeros(0) if D is None else np.ascontiguousarray(D, dtype=np.float64).reshape(-1)
         self._ck(self.lib.aslam_set_camera(self.h, _ptr(K, _dp), _ptr(D, _dp) if D.size else None, int(D.size)))
+
+    def set_detector_params(self, **kw):
+        """cv::aruco::DetectorParameters fields by name; anything not given keeps its OpenCV 3.2.0 default"""
+        p = DetectorParams()
+        self.lib.aslam_default_detector_params(C.byref(p))
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise KeyError(k)
+            setattr(p, k, v)
+        self._ck(self.lib.aslam_set_detector_params(self.h, C.byref(p)))
+
+    def set_dictionary(self, bits, max_correction_bits=0):
+        """bits: n x ms x ms (1 = white); replaces the built-in DICT_ARUCO_ORIGINAL"""
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        self._ck(self.lib.aslam_set_dictionary(self.h, int(b.shape[1]), int(b.shape[0]), int(max_correction_bits), b.ctypes.data_as(C.c_void_p)))
+
+    def set_dictionary_bytes(self, bytes_list, marker_size, max_correction_bits=0):
+        """bytes_list: cv::aruco::Dictionary::bytesList as an n x nbytes x 4 uint8 array"""
+        b = np.ascontiguousarray(bytes_list, dtype=np.uint8)
+        self._ck(self.lib.aslam_set_dictionary_bytes(self.h, int(marker_size), int(b.shape[0]), int(max_correction_bits), b.ctypes.data_as(C.c_void_p)))
 
     def add_encoder(self, wl, wr, t_now):
         self._ck(self.lib.aslam_add_encoder(self.h, float(wl), float(wr), float(t_now)))

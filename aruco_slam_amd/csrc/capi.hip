@@ -75,6 +75,7 @@ struct aslam_ctx {
     SynthMarker* d_synth = nullptr;
     size_t in_frame_bytes = 0, pitch = 0;
     int dict_ms = 5, dict_n = 1024, dict_maxcorr = 0;
+    aslam_detector_params dp{};           // cv::aruco::DetectorParameters in force (defaults of 3.2.0 unless aslam_set_detector_params)
     std::vector<unsigned long long> dict_cells;   // per id: (ms+2)^2 cell image incl. border (for the renderer)
 
     EkfState ekf{};
@@ -160,6 +161,32 @@ void prof_collect(aslam_ctx* c) {
     c->spans.clear();
 }
 
+// codes (4 rotations per id, row-major bit string, first bit most significant - the order k_identify assembles the sampled
+// bits in) and the (ms+2)^2 cell image incl. the black border (renderer) from bits[n][ms*ms], 1 = white
+void make_dict_from_bits(int n, int nm, const uint8_t* bits, std::vector<unsigned long long>& codes, std::vector<unsigned long long>& cells) {
+    codes.assign((size_t)nm * 4, 0ull);
+    cells.assign((size_t)nm * 2, 0ull);
+    const int nc = n + 2;
+    for (int id = 0; id < nm; id++) {
+        const uint8_t* B = bits + (size_t)id * n * n;
+        unsigned long long c[4] = {0, 0, 0, 0};
+        for (int row = 0; row < n; row++)
+            for (int col = 0; col < n; col++) {
+                c[0] = (c[0] << 1) | (unsigned)(B[row * n + col] & 1);
+                c[1] = (c[1] << 1) | (unsigned)(B[col * n + (n - 1 - row)] & 1);
+                c[2] = (c[2] << 1) | (unsigned)(B[(n - 1 - row) * n + (n - 1 - col)] & 1);
+                c[3] = (c[3] << 1) | (unsigned)(B[(n - 1 - col) * n + row] & 1);
+                if (B[row * n + col] & 1) {
+                    const int bit = (row + 1) * nc + col + 1;
+                    cells[(size_t)id * 2 + (bit >> 6)] |= 1ull << (bit & 63);
+                }
+            }
+        for (int r = 0; r < 4; r++) codes[(size_t)id * 4 + r] = c[r];
+    }
+}
+
+int sync_streams(aslam_ctx* c);
+
 int configure_frames(aslam_ctx* c, int rows, int cols, int channels) {
     if (rows <= 0 || cols <= 0 || rows > c->init.max_rows || cols > c->init.max_cols || rows > 4095 || cols > 4095)
         return fail(c, ASLAM_E_INVALID, "frame size outside [1, max_rows x max_cols]");
@@ -168,22 +195,23 @@ int configure_frames(aslam_ctx* c, int rows, int cols, int channels) {
     DetectCfg& g = c->cfg;
     g.rows = rows; g.cols = cols;
     g.pitch = (cols + 63) / 64 * 64;
-    // cv::aruco::DetectorParameters defaults of OpenCV 3.2.0 (the reference passes none, aruco_slam.cpp:313)
-    g.win_r[0] = 1; g.win_r[1] = 6; g.win_r[2] = 11;                     // windows 3, 13, 23
-    g.thresh_c = 7;
-    g.min_perim = (int)(unsigned)(0.03 * std::max(cols, rows));
-    g.max_perim = (int)(unsigned)(4.0 * std::max(cols, rows));
-    g.approx_rate = 0.05;
-    g.min_corner_rate = 0.05;
-    g.min_marker_dist_rate = 0.05;
-    g.min_border_dist = 3;
+    // cv::aruco::DetectorParameters: OpenCV 3.2.0 defaults (the reference passes none, aruco_slam.cpp:313) unless replaced
+    const aslam_detector_params& dp = c->dp;
+    g.win_r[0] = 1; g.win_r[1] = 6; g.win_r[2] = 11;                     // windows 3, 13, 23 (compiled into k_threshold)
+    g.thresh_c = (int)std::floor(dp.adaptiveThreshConstant);             // THRESH_BINARY_INV: src - mean <= -floor(C)
+    g.min_perim = (int)(unsigned)(dp.minMarkerPerimeterRate * std::max(cols, rows));
+    g.max_perim = (int)(unsigned)(dp.maxMarkerPerimeterRate * std::max(cols, rows));
+    g.approx_rate = dp.polygonalApproxAccuracyRate;
+    g.min_corner_rate = dp.minCornerDistanceRate;
+    g.min_marker_dist_rate = dp.minMarkerDistanceRate;
+    g.min_border_dist = dp.minDistanceToBorder;
     g.marker_size = c->dict_ms;
-    g.border_bits = 1;
-    g.cell_margin = (int)(0.13 * kCellPx);
-    g.max_border_err = (int)(c->dict_ms * c->dict_ms * 0.35);
-    g.max_corr = (int)((double)c->dict_maxcorr * 0.6);
+    g.border_bits = dp.markerBorderBits;
+    g.cell_margin = (int)(dp.perspectiveRemoveIgnoredMarginPerCell * kCellPx);
+    g.max_border_err = (int)(c->dict_ms * c->dict_ms * dp.maxErroneousBitsInBorderRate);
+    g.max_corr = (int)((double)c->dict_maxcorr * dp.errorCorrectionRate);
     g.n_dict = c->dict_n;
-    g.min_otsu_std = 5.0;
+    g.min_otsu_std = dp.minOtsuStdDev;
     g.cap_starts = c->init.cap_starts_per_frame;
     g.cap_contours = c->init.cap_contours_per_frame;
     g.cap_points = c->init.cap_points_per_frame;
@@ -311,6 +339,23 @@ int sync_streams(aslam_ctx* c) {
     return ASLAM_OK;
 }
 
+int install_dictionary(aslam_ctx* c, int ms, int n, int maxcorr, const uint8_t* bits) {
+    if (ms < 3 || ms + 2 > kDictMaxCells || n < 1 || n > (1 << 16) || maxcorr < 0 || !bits)
+        return fail(c, ASLAM_E_INVALID, "dictionary: marker size 3..7, 1..65536 markers, maxCorrectionBits >= 0");
+    std::vector<unsigned long long> codes;
+    make_dict_from_bits(ms, n, bits, codes, c->dict_cells);
+    int r = sync_streams(c);
+    if (r) return r;
+    unsigned long long* d_new = nullptr;
+    HIP_TRY(c, dalloc(&d_new, codes.size()));
+    HIP_TRY(c, hipMemcpy(d_new, codes.data(), codes.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    hipFree(c->d_dict);
+    c->d_dict = d_new;
+    c->dict_ms = ms; c->dict_n = n; c->dict_maxcorr = maxcorr;
+    if (c->rows > 0) return configure_frames(c, c->rows, c->cols, c->channels);      // marker size / error budgets follow
+    return ASLAM_OK;
+}
+
 int sync_and_check(aslam_ctx* c) {
     int rs = sync_streams(c);
     if (rs) return rs;
@@ -415,6 +460,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && dalloc(&c->d_enc, (size_t)3 * B) == hipSuccess;
     ok = ok && dalloc(&c->d_synth, 256) == hipSuccess;
     std::vector<unsigned long long> codes;
+    aslam_default_detector_params(&c->dp);
     make_dict_aruco_original(codes, c->dict_cells);
     ok = ok && dalloc(&c->d_dict, codes.size()) == hipSuccess;
     ok = ok && hipMemcpy(c->d_dict, codes.data(), codes.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess;
@@ -528,6 +574,68 @@ int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
 int aslam_sync(aslam_ctx* c) {
     if (!c) return ASLAM_E_INVALID;
     return sync_and_check(c);
+}
+
+void aslam_default_detector_params(aslam_detector_params* p) {
+    if (!p) return;
+    p->adaptiveThreshWinSizeMin = 3; p->adaptiveThreshWinSizeMax = 23; p->adaptiveThreshWinSizeStep = 10;
+    p->adaptiveThreshConstant = 7;
+    p->minMarkerPerimeterRate = 0.03; p->maxMarkerPerimeterRate = 4.0;
+    p->polygonalApproxAccuracyRate = 0.05;            // 3.2.0 (0.03 from 3.3)
+    p->minCornerDistanceRate = 0.05;
+    p->minDistanceToBorder = 3;
+    p->minMarkerDistanceRate = 0.05;
+    p->doCornerRefinement = 0; p->cornerRefinementWinSize = 5; p->cornerRefinementMaxIterations = 30; p->cornerRefinementMinAccuracy = 0.1;
+    p->markerBorderBits = 1;
+    p->perspectiveRemovePixelPerCell = 8;             // 3.2.0 (4 from 3.3)
+    p->perspectiveRemoveIgnoredMarginPerCell = 0.13;
+    p->maxErroneousBitsInBorderRate = 0.35;
+    p->minOtsuStdDev = 5.0;
+    p->errorCorrectionRate = 0.6;
+}
+
+int aslam_set_detector_params(aslam_ctx* c, const aslam_detector_params* p) {
+    if (!c || !p) return ASLAM_E_INVALID;
+    if (p->adaptiveThreshWinSizeMin != 3 || p->adaptiveThreshWinSizeMax != 23 || p->adaptiveThreshWinSizeStep != 10)
+        return fail(c, ASLAM_E_INVALID, "adaptiveThreshWinSize{Min,Max,Step} are compiled in as 3/23/10");
+    if (p->perspectiveRemovePixelPerCell != kCellPx) return fail(c, ASLAM_E_INVALID, "perspectiveRemovePixelPerCell is compiled in as 8");
+    if (p->markerBorderBits != 1) return fail(c, ASLAM_E_INVALID, "markerBorderBits is compiled in as 1");
+    if (p->doCornerRefinement) return fail(c, ASLAM_E_INVALID, "corner refinement is not built (off in the reference)");
+    if (!(p->maxMarkerPerimeterRate > 0 && p->maxMarkerPerimeterRate <= 4.0) || !(p->minMarkerPerimeterRate > 0) ||
+        p->minMarkerPerimeterRate > p->maxMarkerPerimeterRate)
+        return fail(c, ASLAM_E_INVALID, "0 < minMarkerPerimeterRate <= maxMarkerPerimeterRate <= 4");
+    if (!(p->polygonalApproxAccuracyRate > 0) || p->minCornerDistanceRate < 0 || p->minMarkerDistanceRate < 0 || p->minDistanceToBorder < 0 ||
+        p->adaptiveThreshConstant < 0 || p->adaptiveThreshConstant > 255 || p->perspectiveRemoveIgnoredMarginPerCell < 0 ||
+        p->perspectiveRemoveIgnoredMarginPerCell >= 0.5 || p->maxErroneousBitsInBorderRate < 0 || p->errorCorrectionRate < 0 || p->minOtsuStdDev < 0)
+        return fail(c, ASLAM_E_INVALID, "detector parameter out of range");
+    int r = sync_streams(c);
+    if (r) return r;
+    c->dp = *p;
+    if (c->rows > 0) return configure_frames(c, c->rows, c->cols, c->channels);
+    return ASLAM_OK;
+}
+
+int aslam_set_dictionary(aslam_ctx* c, int marker_size, int n_markers, int max_correction_bits, const uint8_t* bits) {
+    if (!c) return ASLAM_E_INVALID;
+    return install_dictionary(c, marker_size, n_markers, max_correction_bits, bits);
+}
+
+int aslam_set_dictionary_bytes(aslam_ctx* c, int marker_size, int n_markers, int max_correction_bits, const uint8_t* bytes_list) {
+    if (!c) return ASLAM_E_INVALID;
+    if (marker_size < 3 || marker_size + 2 > kDictMaxCells || n_markers < 1 || !bytes_list)
+        return fail(c, ASLAM_E_INVALID, "dictionary: marker size 3..7, at least one marker");
+    // cv::aruco::Dictionary::bytesList: n rows x nbytes columns x 4 channels (rotations); channel 0 = the unrotated marker,
+    // bits shifted in first-to-last, so a trailing partial byte holds its bits right-aligned (getByteListFromBits)
+    const int nb = marker_size * marker_size, nbytes = (nb + 7) / 8, rem = nb % 8;
+    std::vector<uint8_t> bits((size_t)n_markers * nb);
+    for (int id = 0; id < n_markers; id++)
+        for (int j = 0; j < nb; j++) {
+            const int b = j / 8, p = j % 8;
+            const unsigned v = bytes_list[((size_t)id * nbytes + b) * 4];
+            const int width = (b == nbytes - 1 && rem) ? rem : 8;
+            bits[(size_t)id * nb + j] = (uint8_t)((v >> (width - 1 - p)) & 1u);
+        }
+    return install_dictionary(c, marker_size, n_markers, max_correction_bits, bits.data());
 }
 
 int aslam_add_encoder(aslam_ctx* c, double wl, double wr, double t_now) {

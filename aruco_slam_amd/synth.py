@@ -216,3 +216,39 @@ def simple_scene(rows, cols, f, n_markers, seed=0, tz=(1.2, 2.6), marker_length=
         poses[i, :9] = R.reshape(-1)
         poses[i, 9:] = t
     return np.array(ids[:n_markers], np.int32), poses, camera_matrix(rows, cols, f)
+
+
+def random_dictionary(marker_size, count, min_distance, seed=0):
+    """bits (count x ms x ms, 1 = white) of a random dictionary whose markers keep a Hamming distance >= min_distance to
+    every rotation of every other marker and to their own rotations (how cv::aruco::generateCustomDictionary selects codes);
+    maxCorrectionBits = (min_distance - 1) // 2."""
+    rng = np.random.RandomState(seed)
+    chosen, rots = [], []
+    while len(chosen) < count:
+        b = rng.randint(0, 2, (marker_size, marker_size)).astype(np.uint8)
+        r = [np.rot90(b, k) for k in range(4)]
+        if any((r[0] != r[k]).sum() < min_distance for k in range(1, 4)):
+            continue
+        if any((b != q).sum() < min_distance for q in rots):
+            continue
+        chosen.append(b)
+        rots.extend(r)
+    return np.stack(chosen), (min_distance - 1) // 2
+
+
+def opencv_bytes_list(bits):
+    """cv::aruco::Dictionary::getByteListFromBits for every marker: n x nbytes x 4 (rotation channels) uint8"""
+    n, ms, _ = bits.shape
+    nbytes = (ms * ms + 7) // 8
+    out = np.zeros((n, nbytes, 4), np.uint8)
+    for i in range(n):
+        for r in range(4):
+            # OpenCV's rotations index the source as (col, n-1-row), (n-1-row, n-1-col), (n-1-col, row): successive rot90(k=1)
+            flat = np.rot90(bits[i], r).reshape(-1)
+            cur, byte = 0, 0
+            for bit in flat:
+                out[i, byte, r] = ((int(out[i, byte, r]) << 1) | int(bit)) & 0xFF
+                cur += 1
+                if cur == 8:
+                    cur, byte = 0, byte + 1
+    return out

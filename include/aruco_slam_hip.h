@@ -69,6 +69,41 @@ const char* aslam_last_error(const aslam_ctx* ctx);
 /* ArucoSlam::setCameraParameters(pair<cv::Mat K, cv::Mat D>) — aruco_slam.h:129-133; K row-major 3x3, D n x 1 */
 int aslam_set_camera(aslam_ctx* ctx, const double K[9], const double* D, int nD);
 
+/* cv::aruco::DetectorParameters (OpenCV 3.2.0 field names and defaults).  The reference passes none (aruco_slam.cpp:313 uses
+ * DetectorParameters::create()), so the defaults are what parity is checked with; this is the knob a maintainer gets
+ * instead of the cv::Ptr.  Compiled-in and therefore rejected when changed: the threshold windows 3/23/10 (LDS tile halo and
+ * box radii), perspectiveRemovePixelPerCell 8, markerBorderBits 1, maxMarkerPerimeterRate above 4 (checkpoint storage per
+ * border walk) and doCornerRefinement (off in the reference, not built). */
+typedef struct {
+    int    adaptiveThreshWinSizeMin, adaptiveThreshWinSizeMax, adaptiveThreshWinSizeStep;
+    double adaptiveThreshConstant;
+    double minMarkerPerimeterRate, maxMarkerPerimeterRate;
+    double polygonalApproxAccuracyRate;
+    double minCornerDistanceRate;
+    int    minDistanceToBorder;
+    double minMarkerDistanceRate;
+    int    doCornerRefinement;
+    int    cornerRefinementWinSize, cornerRefinementMaxIterations;
+    double cornerRefinementMinAccuracy;
+    int    markerBorderBits;
+    int    perspectiveRemovePixelPerCell;
+    double perspectiveRemoveIgnoredMarginPerCell;
+    double maxErroneousBitsInBorderRate;
+    double minOtsuStdDev;
+    double errorCorrectionRate;
+} aslam_detector_params;
+void aslam_default_detector_params(aslam_detector_params* p);
+int  aslam_set_detector_params(aslam_ctx* ctx, const aslam_detector_params* p);
+
+/* dictionary_ = cv::aruco::getPredefinedDictionary(markers_dictionary) — aruco_slam.cpp:11-12, aruco_slam.h:176.  Only
+ * DICT_ARUCO_ORIGINAL (16, the shipped parameters.yaml value) can be generated without OpenCV's tables, so every other
+ * dictionary is handed over as data after aslam_create: either bits[n_markers][marker_size^2] (row-major, 1 = white, what
+ * Dictionary::getBitsFromByteList returns) or OpenCV's own Dictionary::bytesList buffer (n rows x ceil(ms^2/8) columns x
+ * 4 channels, e.g. dictionary->bytesList.data) with dictionary->markerSize / maxCorrectionBits.  marker_size 3..7. */
+int aslam_set_dictionary(aslam_ctx* ctx, int marker_size, int n_markers, int max_correction_bits, const uint8_t* bits);
+int aslam_set_dictionary_bytes(aslam_ctx* ctx, int marker_size, int n_markers, int max_correction_bits,
+                               const uint8_t* bytes_list);
+
 /* ArucoSlam::addEncoder(wl, wr) — aruco_slam.h:116, aruco_slam.cpp:21-74.  t_now_sec stands in for the two
  * ros::Time::now() calls (:26,:31-32); the adapter passes ros::Time::now().toSec(). */
 int aslam_add_encoder(aslam_ctx* ctx, double wl, double wr, double t_now_sec);

@@ -20,7 +20,20 @@ Camera make_cam(const double K[9], const double* D, int nD) {
     for (int i = 0; i < 5; i++) c.D[i] = (i < c.nD && D) ? D[i] : 0.0;
     return c;
 }
-const Dictionary& dict() { static Dictionary d = make_dict_aruco_original(); return d; }
+Dictionary& dict() { static Dictionary d = make_dict_aruco_original(); return d; }
+DetectorParams& params() { static DetectorParams p; return p; }
+// 17 values in the order of struct DetectorParams (oracle.h); NULL = the OpenCV 3.2.0 defaults
+DetectorParams params_from(const double* v) {
+    DetectorParams p;
+    if (!v) return p;
+    p.adaptiveThreshWinSizeMin = (int)v[0]; p.adaptiveThreshWinSizeMax = (int)v[1]; p.adaptiveThreshWinSizeStep = (int)v[2];
+    p.adaptiveThreshConstant = v[3]; p.minMarkerPerimeterRate = v[4]; p.maxMarkerPerimeterRate = v[5];
+    p.polygonalApproxAccuracyRate = v[6]; p.minCornerDistanceRate = v[7]; p.minDistanceToBorder = (int)v[8];
+    p.minMarkerDistanceRate = v[9]; p.markerBorderBits = (int)v[10]; p.perspectiveRemovePixelPerCell = (int)v[11];
+    p.perspectiveRemoveIgnoredMarginPerCell = v[12]; p.maxErroneousBitsInBorderRate = v[13]; p.minOtsuStdDev = v[14];
+    p.errorCorrectionRate = v[15];
+    return p;
+}
 }
 
 extern "C" {
@@ -72,7 +85,7 @@ static int export_candidates(const std::vector<Candidate>& c, int max, float* co
 
 // stage = 0: _detectInitialCandidates; 1: + _reorderCandidatesCorners; 2: + _filterTooCloseCandidates
 int orc_candidates(const uint8_t* gray, int rows, int cols, int stage, int max, float* corners, int* sizes, int* scales, int* keys) {
-    DetectorParams P;
+    const DetectorParams P = params();
     std::vector<Candidate> a, b;
     detect_initial_candidates(gray, rows, cols, P, a);
     if (stage >= 1) reorder_candidate_corners(a);
@@ -87,7 +100,7 @@ void orc_perspective_transform(const float src[8], const float dst[8], double M[
 }
 
 void orc_extract_bits(const uint8_t* gray, int rows, int cols, const float corners[8], uint8_t* bits /*49*/) {
-    DetectorParams P;
+    const DetectorParams P = params();
     Pt2f c[4];
     for (int i = 0; i < 4; i++) c[i] = Pt2f{corners[2 * i], corners[2 * i + 1]};
     std::vector<uint8_t> b;
@@ -96,13 +109,16 @@ void orc_extract_bits(const uint8_t* gray, int rows, int cols, const float corne
 }
 
 int orc_identify(const uint8_t* gray, int rows, int cols, float corners[8], int* id) {
-    DetectorParams P;
+    const DetectorParams P = params();
     Pt2f c[4];
     for (int i = 0; i < 4; i++) c[i] = Pt2f{corners[2 * i], corners[2 * i + 1]};
     bool ok = identify_one_candidate(dict(), gray, rows, cols, c, *id, P);
     for (int i = 0; i < 4; i++) { corners[2 * i] = c[i].x; corners[2 * i + 1] = c[i].y; }
     return ok ? 1 : 0;
 }
+
+// replace the dictionary used by the free functions below (Slam objects carry their own, see orc_slam_set_dictionary)
+void orc_set_dictionary(int ms, int n, int maxcorr, const uint8_t* bits) { dict() = bits ? make_dict_from_bits(ms, n, maxcorr, bits) : make_dict_aruco_original(); }
 
 void orc_dict_bytes(uint8_t* out /*1024*16*/) { std::memcpy(out, dict().bytesList.data(), dict().bytesList.size()); }
 
@@ -116,7 +132,7 @@ void orc_dict_bits(int id, uint8_t* bits25) {
 }
 
 int orc_detect(const uint8_t* img, int rows, int cols, int channels, size_t step, int max, int* ids, float* corners) {
-    DetectorParams P;
+    const DetectorParams P = params();
     std::vector<Detection> det;
     detect_markers(img, rows, cols, channels, step, dict(), P, det);
     int n = (int)std::min<size_t>(det.size(), (size_t)max);
@@ -164,6 +180,11 @@ void* orc_slam_create(const double params[10], float useful_distance_threshold, 
 }
 void orc_slam_destroy(void* h) { delete static_cast<SlamHandle*>(h); }
 void orc_slam_set_camera(void* h, const double K[9], const double* D, int nD) { static_cast<SlamHandle*>(h)->slam.setCamera(make_cam(K, D, nD)); }
+void orc_set_detector_params(const double* v) { params() = params_from(v); }
+void orc_slam_set_detector_params(void* h, const double* v) { static_cast<SlamHandle*>(h)->slam.dp = params_from(v); }
+void orc_slam_set_dictionary(void* h, int ms, int n, int maxcorr, const uint8_t* bits) {
+    static_cast<SlamHandle*>(h)->slam.dict = make_dict_from_bits(ms, n, maxcorr, bits);
+}
 void orc_slam_add_encoder(void* h, double wl, double wr, double t) { static_cast<SlamHandle*>(h)->slam.addEncoder(wl, wr, t); }
 void orc_slam_add_image(void* h, const uint8_t* img, int rows, int cols, int channels, size_t step) {
     SlamHandle* s = static_cast<SlamHandle*>(h);

@@ -539,6 +539,18 @@ Dictionary make_dict_aruco_original() {
     return d;
 }
 
+// A dictionary handed over as data: bits[n][ms*ms] row-major, 1 = white (what cv::aruco::Dictionary::getBitsFromByteList
+// returns per marker).  The rotations are generated here exactly as Dictionary::getByteListFromBits does.
+Dictionary make_dict_from_bits(int markerSize, int nMarkers, int maxCorrectionBits, const uint8_t* bits) {
+    Dictionary d;
+    d.markerSize = markerSize; d.maxCorrectionBits = maxCorrectionBits; d.nMarkers = nMarkers;
+    d.nbytes = (markerSize * markerSize + 7) / 8;
+    d.bytesList.resize((size_t)nMarkers * 4 * d.nbytes);
+    for (int id = 0; id < nMarkers; id++)
+        byte_list_from_bits(bits + (size_t)id * markerSize * markerSize, markerSize, d.nbytes, &d.bytesList[(size_t)id * 4 * d.nbytes]);
+    return d;
+}
+
 // aruco/dictionary.cpp::Dictionary::identify
 bool dictionary_identify(const Dictionary& d, const uint8_t* onlyBits, int& idx, int& rotation, double rate) {
     int maxCorrectionRecalculed = int(double(d.maxCorrectionBits) * rate);

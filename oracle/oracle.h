@@ -97,6 +97,7 @@ int  otsu_threshold(const uint8_t* img, int n);
 void extract_bits(const uint8_t* gray, int rows, int cols, const Pt2f corners[4], int markerSize,
                   const DetectorParams& p, std::vector<uint8_t>& bits);
 Dictionary make_dict_aruco_original();
+Dictionary make_dict_from_bits(int markerSize, int nMarkers, int maxCorrectionBits, const uint8_t* bits);
 bool dictionary_identify(const Dictionary& d, const uint8_t* onlyBits, int& idx, int& rotation, double rate);
 bool identify_one_candidate(const Dictionary& d, const uint8_t* gray, int rows, int cols, Pt2f corners[4],
                             int& id, const DetectorParams& p);

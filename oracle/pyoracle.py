@@ -36,6 +36,10 @@ def load():
         L.orc_slam_destroy.argtypes = [C.c_void_p]
         L.orc_slam_set_camera.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
         L.orc_slam_add_encoder.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.orc_slam_set_dictionary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_set_dictionary.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_set_detector_params.argtypes = [_dp]
+        L.orc_slam_set_detector_params.argtypes = [C.c_void_p, _dp]
         L.orc_slam_add_image.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_size_t]
         L.orc_slam_add_poses.argtypes = [C.c_void_p, C.c_int, _ip, _fp, _dp, _dp]
         L.orc_slam_state_size.argtypes = [C.c_void_p]
@@ -145,6 +149,38 @@ def detect(img, maxn=1024):
     return ids[:n].copy(), corners[:n].copy()
 
 
+PARAM_ORDER = ("adaptiveThreshWinSizeMin", "adaptiveThreshWinSizeMax", "adaptiveThreshWinSizeStep", "adaptiveThreshConstant",
+               "minMarkerPerimeterRate", "maxMarkerPerimeterRate", "polygonalApproxAccuracyRate", "minCornerDistanceRate",
+               "minDistanceToBorder", "minMarkerDistanceRate", "markerBorderBits", "perspectiveRemovePixelPerCell",
+               "perspectiveRemoveIgnoredMarginPerCell", "maxErroneousBitsInBorderRate", "minOtsuStdDev", "errorCorrectionRate")
+PARAM_DEFAULTS = (3, 23, 10, 7.0, 0.03, 4.0, 0.05, 0.05, 3, 0.05, 1, 8, 0.13, 0.35, 5.0, 0.6)
+
+
+def _param_vector(kw):
+    v = dict(zip(PARAM_ORDER, PARAM_DEFAULTS))
+    for k in kw:
+        if k not in v:
+            raise KeyError(k)
+    v.update(kw)
+    return np.array([float(v[k]) for k in PARAM_ORDER])
+
+
+def set_detector_params(**kw):
+    """cv::aruco::DetectorParameters for the free functions; no arguments = OpenCV 3.2.0 defaults"""
+    v = _param_vector(kw)
+    load().orc_set_detector_params(_p(v, _dp))
+
+
+def set_dictionary(bits, max_correction_bits=0):
+    """bits: n x ms x ms array (1 = white) or None for the built-in DICT_ARUCO_ORIGINAL (free functions only)"""
+    L = load()
+    if bits is None:
+        L.orc_set_dictionary(0, 0, 0, None)
+        return
+    b = np.ascontiguousarray(bits, np.uint8)
+    L.orc_set_dictionary(int(b.shape[1]), int(b.shape[0]), int(max_correction_bits), b.ctypes.data_as(C.c_void_p))
+
+
 def dict_bits(i):
     b = np.zeros(25, np.uint8)
     load().orc_dict_bits(int(i), _p(b, _u8p))
@@ -219,6 +255,14 @@ class Slam:
     def set_camera(self, K, D):
         K = np.ascontiguousarray(K, np.float64).reshape(9); D = np.ascontiguousarray(D, np.float64)
         self.L.orc_slam_set_camera(self.h, _p(K, _dp), _p(D, _dp), int(D.size))
+
+    def set_detector_params(self, **kw):
+        v = _param_vector(kw)
+        self.L.orc_slam_set_detector_params(self.h, _p(v, _dp))
+
+    def set_dictionary(self, bits, max_correction_bits=0):
+        b = np.ascontiguousarray(bits, np.uint8)
+        self.L.orc_slam_set_dictionary(self.h, int(b.shape[1]), int(b.shape[0]), int(max_correction_bits), b.ctypes.data_as(C.c_void_p))
 
     def add_encoder(self, wl, wr, t):
         self.L.orc_slam_add_encoder(self.h, float(wl), float(wr), float(t))
