@@ -78,6 +78,11 @@ _SIGS = {
     "aslam_destroy": (None, [C.c_void_p]),
     "aslam_last_error": (C.c_char_p, [C.c_void_p]),
     "aslam_set_camera": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int]),
+    "aslam_stream_open": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "aslam_stream_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double]),
+    "aslam_stream_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "aslam_stream_commit": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
+    "aslam_stream_flush": (C.c_int, [C.c_void_p]),
     "aslam_default_detector_params": (None, [C.c_void_p]),
     "aslam_set_detector_params": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aslam_set_dictionary": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -181,6 +186,28 @@ class Context:
         K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
         D = np.zeros(0) if D is None else np.ascontiguousarray(D, dtype=np.float64).reshape(-1)
         self._ck(self.lib.aslam_set_camera(self.h, _ptr(K, _dp), _ptr(D, _dp) if D.size else None, int(D.size)))
+
+    # -- host-fed stream (pinned ring, asynchronous upload) -------------------------------------
+    def stream_open(self, rows, cols, channels, frames_per_submit):
+        self._ck(self.lib.aslam_stream_open(self.h, int(rows), int(cols), int(channels), int(frames_per_submit)))
+
+    def stream_push(self, img, wl, wr, dt):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        self._ck(self.lib.aslam_stream_push(self.h, img.ctypes.data_as(C.c_void_p), img.strides[0], float(wl), float(wr), float(dt)))
+
+    def stream_slot(self, rows, cols, channels=1):
+        """numpy view of the next pinned slot (fill it, then stream_commit)"""
+        p, st = C.c_void_p(), C.c_size_t()
+        self._ck(self.lib.aslam_stream_acquire(self.h, C.byref(p), C.byref(st)))
+        buf = (C.c_uint8 * (rows * st.value)).from_address(p.value)
+        a = np.frombuffer(buf, np.uint8).reshape(rows, st.value)
+        return a[:, :cols * channels].reshape((rows, cols) if channels == 1 else (rows, cols, channels))
+
+    def stream_commit(self, wl, wr, dt):
+        self._ck(self.lib.aslam_stream_commit(self.h, float(wl), float(wr), float(dt)))
+
+    def stream_flush(self):
+        self._ck(self.lib.aslam_stream_flush(self.h))
 
     def set_detector_params(self, **kw):
         """cv::aruco::DetectorParameters fields by name; anything not given keeps its OpenCV 3.2.0 default"""

@@ -31,6 +31,13 @@ struct aslam_ctx {
     hipStream_t stream = nullptr;         // detection + pose (batched over frames)
     hipStream_t stream_part = nullptr;    // detection beside an EKF chain: CU-masked so that part of every XCD stays free for the chain
     hipStream_t last_detect = nullptr;    // stream of the most recent detection (ordering when it changes)
+    hipStream_t stream_copy = nullptr;    // host-fed stream: uploads from the pinned ring
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_det[2] = {nullptr, nullptr};   // per ring half: upload done / detection done with the slots
+    bool ev_det_set[2] = {false, false}, ev_up_set[2] = {false, false};
+    uint8_t* h_ring = nullptr;            // two half batches of page-locked frames
+    std::vector<double> ring_enc;         // encoder samples of the half being filled
+    int ring_H = 0, ring_half = 0, ring_fill = 0;
+    bool ring_acquired = false;
     hipStream_t stream_ekf = nullptr;     // EKF chain (sequential over frames); overlaps the next batch's detection
     hipEvent_t ev_detect = nullptr, ev_ekf = nullptr;
     int ekf_first = 0, ekf_count = 0;     // slots the in-flight EKF chain still reads
@@ -226,12 +233,13 @@ int check_slot_range(aslam_ctx* c, int first, int count) {
 }
 
 // detection + pose for `count` staged frames starting at slot `first` (asynchronous on the stream)
-int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false) {
+int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipEvent_t wait_before = nullptr) {
     if (c->rows == 0) return fail(c, ASLAM_E_STATE, "no frames staged");
     if (!c->have_cam) return fail(c, ASLAM_E_STATE, "camera parameters not set (aslam_set_camera)");
     hipStream_t st = (beside_ekf && c->stream_part) ? c->stream_part : c->stream;
     if (c->last_detect && c->last_detect != st) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_detect, 0));   // slots / work lists are shared
     c->last_detect = st;
+    if (wait_before) HIP_TRY(c, hipStreamWaitEvent(st, wait_before, 0));          // frames still in flight on the copy stream
     const DetectCfg& g = c->cfg;
     const size_t frame_px = (size_t)g.rows * g.cols;
     const bool alias_gray = c->channels == 1;              // staged gray frames are tight: the detector reads them in place
@@ -332,6 +340,7 @@ int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool 
 }
 
 int sync_streams(aslam_ctx* c) {
+    if (c->stream_copy) HIP_TRY(c, hipStreamSynchronize(c->stream_copy));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->stream_part) HIP_TRY(c, hipStreamSynchronize(c->stream_part));
     HIP_TRY(c, hipStreamSynchronize(c->stream_ekf));
@@ -493,6 +502,9 @@ void aslam_destroy(aslam_ctx* c) {
     ekf_free(c->ekf);
     if (c->ev_detect) hipEventDestroy(c->ev_detect);
     if (c->ev_ekf) hipEventDestroy(c->ev_ekf);
+    if (c->stream_copy) { hipStreamSynchronize(c->stream_copy); hipStreamDestroy(c->stream_copy); }
+    for (int h = 0; h < 2; h++) { if (c->ev_up[h]) hipEventDestroy(c->ev_up[h]); if (c->ev_det[h]) hipEventDestroy(c->ev_det[h]); }
+    if (c->h_ring) hipHostFree(c->h_ring);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->stream_part) hipStreamDestroy(c->stream_part);
     if (c->stream_ekf) hipStreamDestroy(c->stream_ekf);
@@ -541,12 +553,11 @@ int aslam_stage_encoders(aslam_ctx* c, int slot0, int n, const double* wl, const
     return ASLAM_OK;
 }
 
-int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
-    if (!c) return ASLAM_E_INVALID;
+int run_staged(aslam_ctx* c, int first, int count, int with_ekf, hipEvent_t wait_before) {
     int r = check_slot_range(c, first, count);
     if (r) return r;
     if (with_ekf != 2) {                       // 2 = EKF only, on observations already present in the slots (tests)
-        r = run_detect(c, first, count, with_ekf == 1);
+        r = run_detect(c, first, count, with_ekf == 1, wait_before);
         if (r) return r;
     } else {
         if (c->last_detect && c->last_detect != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_detect, 0));
@@ -569,6 +580,97 @@ int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
         c->ekf_count = count;
     }
     return ASLAM_OK;
+}
+
+int aslam_run_staged(aslam_ctx* c, int first, int count, int with_ekf) {
+    if (!c) return ASLAM_E_INVALID;
+    return run_staged(c, first, count, with_ekf, nullptr);
+}
+
+// ---- host-fed stream: pinned ring, asynchronous upload (include/aruco_slam_hip.h) --------------------------------------
+int ring_submit(aslam_ctx* c) {
+    const int n = c->ring_fill, h = c->ring_half, H = c->ring_H;
+    if (n == 0) return ASLAM_OK;
+    const size_t fb = c->in_frame_bytes;
+    const int slot0 = h * H;
+    if (c->ev_det_set[h]) HIP_TRY(c, hipStreamWaitEvent(c->stream_copy, c->ev_det[h], 0));     // the detector still reads these slots
+    HIP_TRY(c, hipMemcpyAsync(c->d_in + (size_t)slot0 * fb, c->h_ring + (size_t)slot0 * fb, (size_t)n * fb, hipMemcpyHostToDevice, c->stream_copy));
+    HIP_TRY(c, hipEventRecord(c->ev_up[h], c->stream_copy));
+    c->ev_up_set[h] = true;
+    c->enc_host.resize((size_t)3 * c->max_batch);
+    std::memcpy(&c->enc_host[(size_t)3 * slot0], c->ring_enc.data(), (size_t)3 * n * sizeof(double));
+    int r = run_staged(c, slot0, n, 1, c->ev_up[h]);
+    if (r) return r;
+    HIP_TRY(c, hipEventRecord(c->ev_det[h], c->last_detect));
+    c->ev_det_set[h] = true;
+    c->ring_half ^= 1;
+    c->ring_fill = 0;
+    // the other half is filled next: its previous upload must have left the pinned memory
+    if (c->ev_up_set[c->ring_half]) HIP_TRY(c, hipEventSynchronize(c->ev_up[c->ring_half]));
+    return ASLAM_OK;
+}
+
+int aslam_stream_open(aslam_ctx* c, int rows, int cols, int channels, int frames_per_submit) {
+    if (!c) return ASLAM_E_INVALID;
+    if (frames_per_submit < 1 || 2 * frames_per_submit > c->max_batch) return fail(c, ASLAM_E_INVALID, "frames_per_submit must be in [1, max_batch / 2]");
+    int r = sync_streams(c);
+    if (r) return r;
+    r = configure_frames(c, rows, cols, channels);
+    if (r) return r;
+    c->in_frame_bytes = (size_t)rows * cols * channels;
+    if (c->h_ring) { hipHostFree(c->h_ring); c->h_ring = nullptr; }
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_ring), (size_t)2 * frames_per_submit * c->in_frame_bytes, hipHostMallocDefault));
+    if (!c->stream_copy) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+        for (int h = 0; h < 2; h++) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_up[h], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_det[h], hipEventDisableTiming));
+        }
+    }
+    c->ev_det_set[0] = c->ev_det_set[1] = c->ev_up_set[0] = c->ev_up_set[1] = false;
+    c->ring_H = frames_per_submit; c->ring_half = 0; c->ring_fill = 0; c->ring_acquired = false;
+    c->ring_enc.assign((size_t)3 * frames_per_submit, 0.0);
+    return ASLAM_OK;
+}
+
+int aslam_stream_acquire(aslam_ctx* c, uint8_t** px, size_t* step) {
+    if (!c || !px) return ASLAM_E_INVALID;
+    if (!c->h_ring) return fail(c, ASLAM_E_STATE, "aslam_stream_open first");
+    if (!c->have_cam) return fail(c, ASLAM_E_STATE, "camera parameters not set (aslam_set_camera)");
+    *px = c->h_ring + ((size_t)c->ring_half * c->ring_H + c->ring_fill) * c->in_frame_bytes;
+    if (step) *step = (size_t)c->cols * c->channels;
+    c->ring_acquired = true;
+    return ASLAM_OK;
+}
+
+int aslam_stream_commit(aslam_ctx* c, double wl, double wr, double dt) {
+    if (!c) return ASLAM_E_INVALID;
+    if (!c->ring_acquired) return fail(c, ASLAM_E_STATE, "aslam_stream_acquire first");
+    c->ring_acquired = false;
+    double* e = &c->ring_enc[(size_t)3 * c->ring_fill];
+    e[0] = wl; e[1] = wr; e[2] = dt;
+    if (++c->ring_fill == c->ring_H) return ring_submit(c);
+    return ASLAM_OK;
+}
+
+int aslam_stream_push(aslam_ctx* c, const uint8_t* px, size_t step, double wl, double wr, double dt) {
+    if (!c || !px) return ASLAM_E_INVALID;
+    uint8_t* dst = nullptr;
+    size_t dstep = 0;
+    int r = aslam_stream_acquire(c, &dst, &dstep);
+    if (r) return r;
+    if (step < dstep) { c->ring_acquired = false; return fail(c, ASLAM_E_INVALID, "step smaller than a row"); }
+    if (step == dstep) std::memcpy(dst, px, (size_t)c->rows * dstep);
+    else for (int y = 0; y < c->rows; y++) std::memcpy(dst + (size_t)y * dstep, px + (size_t)y * step, dstep);
+    return aslam_stream_commit(c, wl, wr, dt);
+}
+
+int aslam_stream_flush(aslam_ctx* c) {
+    if (!c) return ASLAM_E_INVALID;
+    if (!c->h_ring) return fail(c, ASLAM_E_STATE, "aslam_stream_open first");
+    int r = ring_submit(c);
+    if (r) return r;
+    return sync_and_check(c);
 }
 
 int aslam_sync(aslam_ctx* c) {

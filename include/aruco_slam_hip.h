@@ -142,6 +142,19 @@ int aslam_sync(aslam_ctx* ctx);
 int aslam_get_slot_detections(aslam_ctx* ctx, int slot, int* M, int* ids, float* corners, double* rvecs, double* tvecs);
 int aslam_get_slot_raw_observations(aslam_ctx* ctx, int slot, int* n, int* ids, int* valid, double* xyth, double* Rdiag);
 
+/* ---- host-fed stream: pinned ring + asynchronous upload (the input step before the path, aruco_slam_node.cpp:85-96) ----
+ * aslam_stream_open page-locks a ring of two half batches of frames_per_submit frames (<= max_batch / 2).
+ * aslam_stream_push copies one frame and the encoder sample (wl, wr, dt) that precedes it into the ring (px is borrowed
+ * for the call only); aslam_stream_acquire / aslam_stream_commit hand the pinned slot to the producer instead (no host
+ * copy).  Every frames_per_submit frames the half is uploaded on a copy stream and its detection + EKF steps are
+ * enqueued, so the upload of one half overlaps the processing of the other; the calls only block when the ring is full.
+ * aslam_stream_flush submits what is pending, waits and reports device-side overflow; then the getters are valid. */
+int aslam_stream_open(aslam_ctx* ctx, int rows, int cols, int channels, int frames_per_submit);
+int aslam_stream_push(aslam_ctx* ctx, const uint8_t* px, size_t step_bytes, double wl, double wr, double dt);
+int aslam_stream_acquire(aslam_ctx* ctx, uint8_t** px, size_t* step_bytes);
+int aslam_stream_commit(aslam_ctx* ctx, double wl, double wr, double dt);
+int aslam_stream_flush(aslam_ctx* ctx);
+
 /* cv::aruco::detectMarkers + estimatePoseSingleMarkers on a batch of independent host frames, no EKF
  * (BASELINE config 5).  counts[nframes]; ids/corners/rvecs/tvecs hold max_per_frame entries per frame. */
 int aslam_detect_batch(aslam_ctx* ctx, const uint8_t* frames, int nframes, int rows, int cols, int channels,

@@ -200,6 +200,7 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { std::strcpy(
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); if (*p) std::memset(*p, 0xCD, n); return *p ? hipSuccess : hipErrorInvalidValue; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+constexpr unsigned hipHostMallocDefault = 0;
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n ? n : 1); return hipSuccess; }
 template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f = 0) { return hipHostMalloc(reinterpret_cast<void**>(p), n, f); }
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
@@ -214,6 +215,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
 enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(1); return hipSuccess; }
 inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

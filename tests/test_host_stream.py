@@ -1,0 +1,55 @@
+"""Host-fed stream API (pinned ring + asynchronous upload): same frames, same order => same detections and the
+same filter state as the staged API; partial halves, ring wrap-around, zero-copy slots."""
+import numpy as np
+import pytest
+
+from aruco_slam_amd import capi, synth
+
+
+def _run(cfg, n_frames, H, zero_copy, waves):
+    w = synth.PanelWorld(cfg)
+    frs = [w.frame(i) for i in range(n_frames)]
+    kw = dict(max_rows=cfg.rows, max_cols=cfg.cols, max_landmarks=w.L + 8, persistent_waves=waves)
+    a = capi.Context(max_batch=n_frames, **kw)
+    b = capi.Context(max_batch=2 * H, **kw)
+    for c in (a, b):
+        c.set_camera(w.K, np.zeros(5))
+    imgs = [a.synth_render(i, cfg.rows, cfg.cols, w.K, fr.ids, fr.poses, noise_amp=2, seed=i) for i, fr in enumerate(frs)]
+    a.stage_encoders([f.wl for f in frs], [f.wr for f in frs], [f.dt for f in frs])
+    a.run_staged(0, n_frames, with_ekf=True)
+    a.sync()
+    b.stream_open(cfg.rows, cfg.cols, 1, H)
+    for img, fr in zip(imgs, frs):
+        if zero_copy:
+            b.stream_slot(cfg.rows, cfg.cols)[:] = img
+            b.stream_commit(fr.wl, fr.wr, fr.dt)
+        else:
+            b.stream_push(img, fr.wl, fr.wr, fr.dt)
+    b.stream_flush()
+    mu_a, S_a = a.get_state()
+    mu_b, S_b = b.get_state()
+    assert np.array_equal(mu_a, mu_b) and np.array_equal(S_a, S_b)
+    assert np.array_equal(a.get_landmark_ids(), b.get_landmark_ids())
+    da, db = a.get_detections(), b.get_detections()            # last frame
+    assert len(da[0]) > 0 and all(np.array_equal(x, y) for x, y in zip(da, db))
+
+
+@pytest.mark.parametrize("n_frames,H,zero_copy", [(7, 2, False), (6, 3, True), (3, 4, False)])
+def test_stream_equals_staged_small(n_frames, H, zero_copy):
+    _run(synth.CONFIGS["cfg1"], n_frames, H, zero_copy, 4)
+
+
+def test_stream_needs_open_and_camera():
+    c = capi.Context(max_rows=64, max_cols=64, max_batch=4, persistent_waves=4, max_landmarks=16)
+    with pytest.raises(capi.AslamError):
+        c.stream_push(np.zeros((64, 64), np.uint8), 0, 0, 0)
+    with pytest.raises(capi.AslamError):
+        c.stream_open(64, 64, 1, 3)                             # 2 * 3 > max_batch
+    c.stream_open(64, 64, 1, 2)
+    with pytest.raises(capi.AslamError):
+        c.stream_push(np.zeros((64, 64), np.uint8), 0, 0, 0)    # camera parameters missing
+
+
+@pytest.mark.gpu
+def test_stream_equals_staged_cfg2():
+    _run(synth.CONFIGS["cfg2"], 50, 12, False, 0)
