@@ -63,6 +63,15 @@ class DetectorParams(C.Structure):
     ]
 
 
+class PoseMsg(C.Structure):
+    _fields_ = [("position", C.c_double * 3), ("orientation", C.c_double * 4), ("covariance", C.c_double * 36)]
+
+
+class MarkerMsg(C.Structure):
+    _fields_ = [("id", C.c_int), ("pad", C.c_int), ("scale", C.c_double * 3), ("color", C.c_float * 4), ("position", C.c_double * 3),
+                ("orientation", C.c_double * 4), ("lifetime_sec", C.c_double)]
+
+
 class AslamError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"aslam error {code} ({E_NAMES.get(code, '?')}): {msg}")
@@ -78,6 +87,11 @@ _SIGS = {
     "aslam_destroy": (None, [C.c_void_p]),
     "aslam_last_error": (C.c_char_p, [C.c_void_p]),
     "aslam_set_camera": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int]),
+    "aslam_get_pose_msg": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "aslam_get_map_markers": (C.c_int, [C.c_void_p, C.c_int, _ip, C.c_void_p]),
+    "aslam_get_detected_markers": (C.c_int, [C.c_void_p, C.c_int, _ip, C.c_void_p]),
+    "aslam_save_state": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "aslam_load_state": (C.c_int, [C.c_void_p, C.c_char_p]),
     "aslam_stream_open": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "aslam_stream_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double]),
     "aslam_stream_acquire": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
@@ -186,6 +200,32 @@ class Context:
         K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
         D = np.zeros(0) if D is None else np.ascontiguousarray(D, dtype=np.float64).reshape(-1)
         self._ck(self.lib.aslam_set_camera(self.h, _ptr(K, _dp), _ptr(D, _dp) if D.size else None, int(D.size)))
+
+    # -- what the node publishes / persistence --------------------------------------------------
+    def pose_msg(self):
+        m = PoseMsg()
+        self._ck(self.lib.aslam_get_pose_msg(self.h, C.byref(m)))
+        return np.array(m.position), np.array(m.orientation), np.array(m.covariance).reshape(6, 6)
+
+    def _markers(self, fn):
+        n = C.c_int(0)
+        self._ck(fn(self.h, 0, C.byref(n), None))
+        arr = (MarkerMsg * max(n.value, 1))()
+        self._ck(fn(self.h, n.value, C.byref(n), arr))
+        return [dict(id=a.id, scale=tuple(a.scale), color=tuple(a.color), position=np.array(a.position), orientation=np.array(a.orientation),
+                     lifetime=a.lifetime_sec) for a in arr[:n.value]]
+
+    def map_markers(self):
+        return self._markers(self.lib.aslam_get_map_markers)
+
+    def detected_markers(self):
+        return self._markers(self.lib.aslam_get_detected_markers)
+
+    def save_state(self, path):
+        self._ck(self.lib.aslam_save_state(self.h, str(path).encode()))
+
+    def load_state(self, path):
+        self._ck(self.lib.aslam_load_state(self.h, str(path).encode()))
 
     # -- host-fed stream (pinned ring, asynchronous upload) -------------------------------------
     def stream_open(self, rows, cols, channels, frames_per_submit):

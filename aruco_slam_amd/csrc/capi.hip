@@ -8,6 +8,8 @@
 #include "../../include/aruco_slam_hip.h"
 #include <string>
 #include <vector>
+#include <cfloat>
+#include <cstdio>
 #include <cstring>
 #include <cstdio>
 #include <cmath>
@@ -805,6 +807,183 @@ int aslam_set_state(aslam_ctx* c, int N, const double* mu, const double* sigma, 
     HIP_TRY(c, hipMemcpy(c->ekf.d_L, &L, sizeof(int), hipMemcpyHostToDevice));
     int zero = 0;
     HIP_TRY(c, hipMemcpy(c->ekf.d_nlast, &zero, sizeof(int), hipMemcpyHostToDevice));
+    return ASLAM_OK;
+}
+
+// ---- host-side result surface (what the node publishes; pure host arithmetic on a few values read back) ---------------
+namespace {
+// tf2::Quaternion::setRPY(roll, pitch, yaw) -> (x, y, z, w)
+void quat_from_rpy(double roll, double pitch, double yaw, double q[4]) {
+    const double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+    const double cy = std::cos(hy), sy = std::sin(hy), cp = std::cos(hp), sp = std::sin(hp), cr = std::cos(hr), sr = std::sin(hr);
+    q[0] = sr * cp * cy - cr * sp * sy;
+    q[1] = cr * sp * cy + sr * cp * sy;
+    q[2] = cr * cp * sy - sr * sp * cy;
+    q[3] = cr * cp * cy + sr * sp * sy;
+}
+// cv::Rodrigues (vector -> matrix), row-major
+void rodrigues_host(const double r[3], double R[9]) {
+    const double th = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (th < DBL_EPSILON) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+    const double c = std::cos(th), s = std::sin(th), c1 = 1.0 - c, it = 1.0 / th;
+    const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+    R[0] = c + c1 * x * x;     R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y;     R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+}
+// tf2::Matrix3x3::getRotation
+void quat_from_matrix(const double m[9], double q[4]) {
+    const double trace = m[0] + m[4] + m[8];
+    if (trace > 0.0) {
+        double s = std::sqrt(trace + 1.0);
+        q[3] = s * 0.5;
+        s = 0.5 / s;
+        q[0] = (m[7] - m[5]) * s; q[1] = (m[2] - m[6]) * s; q[2] = (m[3] - m[1]) * s;
+    } else {
+        const int i = m[0] < m[4] ? (m[4] < m[8] ? 2 : 1) : (m[0] < m[8] ? 2 : 0);
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        double s = std::sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+        q[i] = s * 0.5;
+        s = 0.5 / s;
+        q[3] = (m[k * 3 + j] - m[j * 3 + k]) * s;
+        q[j] = (m[j * 3 + i] + m[i * 3 + j]) * s;
+        q[k] = (m[k * 3 + i] + m[i * 3 + k]) * s;
+    }
+}
+void quat_mul(const double a[4], const double b[4], double o[4]) {          // Hamilton product, (x, y, z, w)
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+void quat_rotate(const double q[4], const double v[3], double o[3]) {        // tf2::Matrix3x3(q) * v
+    const double d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3], s = 2.0 / d;
+    const double xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+    const double wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs, xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs, yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+    o[0] = (1.0 - (yy + zz)) * v[0] + (xy - wz) * v[1] + (xz + wy) * v[2];
+    o[1] = (xy + wz) * v[0] + (1.0 - (xx + zz)) * v[1] + (yz - wx) * v[2];
+    o[2] = (xz - wy) * v[0] + (yz + wx) * v[1] + (1.0 - (xx + yy)) * v[2];
+}
+void fill_marker(aslam_marker_msg& m, int id, double length, double x, double y, double z, const double q[4], float r, float g, float b,
+                 float a, double lifetime) {                                 // ArucoSlam::GenerateMarker, aruco_slam.cpp:289-305
+    m.id = id;
+    m.scale[0] = length; m.scale[1] = length; m.scale[2] = 0.01;
+    m.color[0] = r; m.color[1] = g; m.color[2] = b; m.color[3] = a;
+    m.position[0] = x; m.position[1] = y; m.position[2] = z;
+    for (int k = 0; k < 4; k++) m.orientation[k] = q[k];
+    m.lifetime_sec = lifetime;
+}
+}  // namespace
+
+int aslam_get_pose_msg(aslam_ctx* c, aslam_pose_msg* out) {                   // ArucoSlam::toRosPose, aruco_slam.cpp:378-410
+    if (!c || !out) return fail(c, ASLAM_E_INVALID, "null argument");
+    { int rs = sync_streams(c); if (rs) return rs; }
+    double mu[3], S[9];
+    HIP_TRY(c, hipMemcpy(mu, c->ekf.d_mu, sizeof(mu), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy2D(S, 3 * sizeof(double), c->ekf.d_sigma, (size_t)c->ekf.ld * sizeof(double), 3 * sizeof(double), 3, hipMemcpyDeviceToHost));
+    // S[col * 3 + row]
+    out->position[0] = mu[0]; out->position[1] = mu[1]; out->position[2] = 0.1;
+    quat_from_rpy(0, 0, mu[2], out->orientation);
+    for (int i = 0; i < 36; i++) out->covariance[i] = 0.0;
+    static const int at[3] = {0, 1, 5};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out->covariance[at[i] * 6 + at[j]] = S[j * 3 + i];     // sigma_(i, j)
+    return ASLAM_OK;
+}
+
+int aslam_get_map_markers(aslam_ctx* c, int max, int* n, aslam_marker_msg* out) {   // detected_map_, aruco_slam.cpp:265-281
+    if (!c || !n) return fail(c, ASLAM_E_INVALID, "null argument");
+    { int rs = sync_streams(c); if (rs) return rs; }
+    int L = 0;
+    HIP_TRY(c, hipMemcpy(&L, c->ekf.d_L, sizeof(int), hipMemcpyDeviceToHost));
+    *n = L;
+    if (!out || L == 0) return ASLAM_OK;
+    std::vector<double> mu((size_t)3 + 3 * L);
+    HIP_TRY(c, hipMemcpy(mu.data(), c->ekf.d_mu, mu.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < L && i < max; i++) {
+        double q[4];
+        quat_from_rpy(0, 1.5708, mu[3 * i + 5], q);
+        fill_marker(out[i], i, c->sp.marker_length, mu[3 * i + 3], mu[3 * i + 4], 0.3, q, 1.f, 0.5f, 1.f, 0.5f, 0.0);
+    }
+    return ASLAM_OK;
+}
+
+int aslam_get_detected_markers(aslam_ctx* c, int max, int* n, aslam_marker_msg* out) {   // detected_markers_, aruco_slam.cpp:325-347
+    if (!c || !n) return fail(c, ASLAM_E_INVALID, "null argument");
+    int M = 0;
+    int r = aslam_get_detections(c, &M, nullptr, nullptr, nullptr, nullptr);
+    if (r) return r;
+    std::vector<int> ids(M);
+    std::vector<double> rv((size_t)3 * M), tv((size_t)3 * M);
+    if (M) { r = aslam_get_detections(c, &M, ids.data(), nullptr, rv.data(), tv.data()); if (r) return r; }
+    int k = 0;
+    for (int i = 0; i < M; i++) {
+        const double* t = &tv[(size_t)3 * i];
+        // the range gate precedes the visualisation (aruco_slam.cpp:327-333): float norm against the float threshold
+        if ((float)std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) > c->sp.useful_distance_threshold) continue;
+        if (out && k < max) {
+            double R[9], q[4], qo[4], p[3];
+            rodrigues_host(&rv[(size_t)3 * i], R);
+            quat_from_matrix(R, q);                                    // fillTransform + getRotation
+            quat_rotate(c->init.r2c_q, t, p);                           // tf2::doTransform(pose, pose, transformStamped_r2c_)
+            for (int a = 0; a < 3; a++) p[a] += c->init.r2c_t[a];
+            quat_mul(c->init.r2c_q, q, qo);
+            fill_marker(out[k], ids[i], c->sp.marker_length, p[0], p[1], p[2], qo, 1.f, 0.f, 0.f, 1.f, 0.1);
+        }
+        k++;
+    }
+    *n = k;
+    return ASLAM_OK;
+}
+
+// ---- persistence (no counterpart in the reference: warm starts of large maps) ----------------------------
+int aslam_save_state(aslam_ctx* c, const char* path) {
+    if (!c || !path) return fail(c, ASLAM_E_INVALID, "null argument");
+    int N = 0;
+    int r = aslam_get_state(c, &N, nullptr, nullptr);
+    if (r) return r;
+    const int L = (N - 3) / 3;
+    std::vector<double> mu(N), S((size_t)N * N);
+    std::vector<int> ids(std::max(L, 1));
+    r = aslam_get_state(c, &N, mu.data(), S.data());
+    if (r) return r;
+    int L2 = 0;
+    r = aslam_get_landmark_ids(c, &L2, ids.data());
+    if (r) return r;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(c, ASLAM_E_INVALID, std::string("cannot write ") + path);
+    const char magic[8] = {'A', 'S', 'L', 'A', 'M', 'S', 'T', '1'};
+    const int hdr[2] = {N, c->is_init ? 1 : 0};
+    bool ok = std::fwrite(magic, 1, 8, f) == 8 && std::fwrite(hdr, sizeof(int), 2, f) == 2 &&
+              std::fwrite(mu.data(), sizeof(double), mu.size(), f) == mu.size() &&
+              std::fwrite(S.data(), sizeof(double), S.size(), f) == S.size() &&
+              std::fwrite(ids.data(), sizeof(int), (size_t)L, f) == (size_t)L;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? ASLAM_OK : fail(c, ASLAM_E_INVALID, std::string("short write to ") + path);
+}
+
+int aslam_load_state(aslam_ctx* c, const char* path) {
+    if (!c || !path) return fail(c, ASLAM_E_INVALID, "null argument");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(c, ASLAM_E_INVALID, std::string("cannot read ") + path);
+    char magic[8];
+    int hdr[2] = {0, 0};
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "ASLAMST1", 8) == 0 && std::fread(hdr, sizeof(int), 2, f) == 2;
+    const int N = hdr[0];
+    ok = ok && N >= 3 && (N - 3) % 3 == 0 && (N - 3) / 3 <= c->ekf.max_landmarks;
+    std::vector<double> mu, S;
+    std::vector<int> ids;
+    if (ok) {
+        const int L = (N - 3) / 3;
+        mu.resize(N); S.resize((size_t)N * N); ids.resize(std::max(L, 1));
+        ok = std::fread(mu.data(), sizeof(double), mu.size(), f) == mu.size() && std::fread(S.data(), sizeof(double), S.size(), f) == S.size() &&
+             std::fread(ids.data(), sizeof(int), (size_t)L, f) == (size_t)L;
+    }
+    std::fclose(f);
+    if (!ok) return fail(c, ASLAM_E_INVALID, std::string("not a state file that fits this context: ") + path);
+    int r = aslam_set_state(c, N, mu.data(), S.data(), ids.data());
+    if (r) return r;
+    c->is_init = hdr[1] != 0;
     return ASLAM_OK;
 }
 

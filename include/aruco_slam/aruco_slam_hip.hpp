@@ -2,9 +2,10 @@
 // (include/aruco_slam/aruco_slam.h:101-193) on top of the POD-only C-ABI (include/aruco_slam_hip.h).
 //
 // The POD overloads compile anywhere (this image has neither OpenCV, Eigen nor ROS).  Where <opencv2/core.hpp> is
-// available the `cv::Mat` overloads with the reference's exact signatures are enabled; the visualisation getters
-// (toRosPose / toRosDetectedMarkers / toRosMappedMarkers, aruco_slam.cpp:265-305,378-410) are host-side message
-// assembly from the getters below and are a "next" row, not part of the hot path.
+// available the `cv::Mat` overloads with the reference's exact signatures are enabled.  The visualisation getters
+// (toRosPose / toRosDetectedMarkers / toRosMappedMarkers, aruco_slam.cpp:265-305,378-410) return the message CONTENT as
+// plain structs (aslam_pose_msg / aslam_marker_msg); where the ROS message headers exist, the overloads at the bottom copy
+// them field by field into geometry_msgs / visualization_msgs types.
 #pragma once
 #include "../aruco_slam_hip.h"
 #include <stdexcept>
@@ -103,6 +104,18 @@ public:
         }
         return out;
     }
+    // geometry_msgs::PoseWithCovarianceStamped toRosPose() — aruco_slam.h:151: frame "world", content as plain data
+    aslam_pose_msg toRosPoseData() { aslam_pose_msg m; check(aslam_get_pose_msg(ctx_, &m)); return m; }
+    // visualization_msgs::MarkerArray toRosMappedMarkers() — aruco_slam.h:145 (detected_map_, frame "world")
+    std::vector<aslam_marker_msg> toRosMappedMarkersData() { return markers(aslam_get_map_markers); }
+    // visualization_msgs::MarkerArray toRosDetectedMarkers() — aruco_slam.h:139 (detected_markers_, frame "base_link")
+    std::vector<aslam_marker_msg> toRosDetectedMarkersData() { return markers(aslam_get_detected_markers); }
+    // cv::aruco::getPredefinedDictionary stand-ins and DetectorParameters (aruco_slam.cpp:11-12, 313)
+    void setDictionary(int markerSize, int nMarkers, int maxCorrectionBits, const unsigned char* bytesList) {
+        check(aslam_set_dictionary_bytes(ctx_, markerSize, nMarkers, maxCorrectionBits, bytesList));
+    }
+    void setDetectorParameters(const aslam_detector_params& p) { check(aslam_set_detector_params(ctx_, &p)); }
+
     std::vector<int> landmarkIds() {                              // aruco_id_map (aruco_slam.h:164), by landmark index
         int L = 0;
         check(aslam_get_landmark_ids(ctx_, &L, nullptr));
@@ -113,8 +126,53 @@ public:
     aslam_ctx* handle() { return ctx_; }
 
 private:
+    std::vector<aslam_marker_msg> markers(int (*fn)(aslam_ctx*, int, int*, aslam_marker_msg*)) {
+        int n = 0;
+        check(fn(ctx_, 0, &n, nullptr));
+        std::vector<aslam_marker_msg> out(n);
+        if (n) check(fn(ctx_, n, &n, out.data()));
+        out.resize(n);
+        return out;
+    }
     void check(int rc) { if (rc != ASLAM_OK) throw std::runtime_error(std::string("aruco_slam_hip: ") + aslam_last_error(ctx_)); }
     aslam_ctx* ctx_ = nullptr;
 };
+
+#if defined(__has_include)
+#if __has_include(<geometry_msgs/PoseWithCovarianceStamped.h>) && __has_include(<visualization_msgs/MarkerArray.h>)
+} // namespace aruco_slam_hip
+#include <geometry_msgs/PoseWithCovarianceStamped.h>
+#include <visualization_msgs/MarkerArray.h>
+#include <ros/duration.h>
+namespace aruco_slam_hip {
+inline geometry_msgs::PoseWithCovarianceStamped toRosPose(ArucoSlam& s) {                      // aruco_slam.cpp:378-410
+    const aslam_pose_msg m = s.toRosPoseData();
+    geometry_msgs::PoseWithCovarianceStamped r;
+    r.header.frame_id = "world";
+    r.pose.pose.position.x = m.position[0]; r.pose.pose.position.y = m.position[1]; r.pose.pose.position.z = m.position[2];
+    r.pose.pose.orientation.x = m.orientation[0]; r.pose.pose.orientation.y = m.orientation[1];
+    r.pose.pose.orientation.z = m.orientation[2]; r.pose.pose.orientation.w = m.orientation[3];
+    for (int i = 0; i < 36; i++) r.pose.covariance[i] = m.covariance[i];
+    return r;
+}
+inline visualization_msgs::MarkerArray toRosMarkers(const std::vector<aslam_marker_msg>& v, const char* frame) {   // GenerateMarker, :289-305
+    visualization_msgs::MarkerArray a;
+    for (const aslam_marker_msg& m : v) {
+        visualization_msgs::Marker k;
+        k.id = m.id; k.header.frame_id = frame; k.type = visualization_msgs::Marker::CUBE;
+        k.scale.x = m.scale[0]; k.scale.y = m.scale[1]; k.scale.z = m.scale[2];
+        k.color.r = m.color[0]; k.color.g = m.color[1]; k.color.b = m.color[2]; k.color.a = m.color[3];
+        k.pose.position.x = m.position[0]; k.pose.position.y = m.position[1]; k.pose.position.z = m.position[2];
+        k.pose.orientation.x = m.orientation[0]; k.pose.orientation.y = m.orientation[1];
+        k.pose.orientation.z = m.orientation[2]; k.pose.orientation.w = m.orientation[3];
+        k.lifetime = ros::Duration(m.lifetime_sec);
+        a.markers.push_back(k);
+    }
+    return a;
+}
+inline visualization_msgs::MarkerArray toRosMappedMarkers(ArucoSlam& s) { return toRosMarkers(s.toRosMappedMarkersData(), "world"); }
+inline visualization_msgs::MarkerArray toRosDetectedMarkers(ArucoSlam& s) { return toRosMarkers(s.toRosDetectedMarkersData(), "base_link"); }
+#endif
+#endif
 
 } // namespace aruco_slam_hip

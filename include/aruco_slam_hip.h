@@ -142,6 +142,24 @@ int aslam_sync(aslam_ctx* ctx);
 int aslam_get_slot_detections(aslam_ctx* ctx, int slot, int* M, int* ids, float* corners, double* rvecs, double* tvecs);
 int aslam_get_slot_raw_observations(aslam_ctx* ctx, int slot, int* n, int* ids, int* valid, double* xyth, double* Rdiag);
 
+/* ---- what the node publishes (aruco_slam_node.cpp:99-118), as plain data for the adapter to wrap in ROS messages ----
+ * aslam_get_pose_msg = ArucoSlam::toRosPose (aruco_slam.cpp:378-410): frame "world", z = 0.1, yaw-only quaternion
+ * (x, y, z, w) and the 6x6 row-major covariance with sigma_(0..2, 0..2) scattered to rows/columns 0, 1, 5.
+ * aslam_get_map_markers = detected_map_ (aruco_slam.cpp:265-281): frame "world", CUBE (L, L, 0.01), rgba (1, .5, 1, .5),
+ * z = 0.3, setRPY(0, 1.5708, theta), lifetime 0; id = landmark index.
+ * aslam_get_detected_markers = detected_markers_ of the last frame (aruco_slam.cpp:325-347): markers inside the range gate,
+ * frame "base_link", rgba (1, 0, 0, 1), pose = transformStamped_r2c applied to (rvec, tvec), lifetime 0.1 s.
+ * *n receives the number available; at most max are written. */
+typedef struct { double position[3]; double orientation[4]; double covariance[36]; } aslam_pose_msg;
+typedef struct { int id; int pad; double scale[3]; float color[4]; double position[3]; double orientation[4]; double lifetime_sec; } aslam_marker_msg;
+int aslam_get_pose_msg(aslam_ctx* ctx, aslam_pose_msg* out);
+int aslam_get_map_markers(aslam_ctx* ctx, int max, int* n, aslam_marker_msg* out);
+int aslam_get_detected_markers(aslam_ctx* ctx, int max, int* n, aslam_marker_msg* out);
+
+/* filter state (mu, sigma, landmark ids, armed flag) to / from a file; no counterpart in the reference (warm starts) */
+int aslam_save_state(aslam_ctx* ctx, const char* path);
+int aslam_load_state(aslam_ctx* ctx, const char* path);
+
 /* ---- host-fed stream: pinned ring + asynchronous upload (the input step before the path, aruco_slam_node.cpp:85-96) ----
  * aslam_stream_open page-locks a ring of two half batches of frames_per_submit frames (<= max_batch / 2).
  * aslam_stream_push copies one frame and the encoder sample (wl, wr, dt) that precedes it into the ring (px is borrowed

@@ -206,6 +206,10 @@ template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned f =
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2D(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind) {
+    for (size_t y = 0; y < h; y++) std::memcpy((char*)d + y * dp, (const char*)s + y * sp, w);
+    return hipSuccess;
+}
 inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
     for (size_t y = 0; y < h; y++) std::memmove((char*)d + y * dp, (const char*)s + y * sp, w);
     return hipSuccess;
