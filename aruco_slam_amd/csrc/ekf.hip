@@ -55,6 +55,26 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
                               double* sH /*shared 9*/, double* sQ /*shared 9*/, double* sMu /*shared 3*/) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int ld = E.ld;
+    // every load of the pass is issued before the first dependent instruction: the three pose rows / columns of this
+    // thread's landmark columns (up to kPredCols of them in registers) and, on thread 0, the pose block itself
+    constexpr int kPredCols = 4;
+    double ca[kPredCols], cb[kPredCols], cc[kPredCols], ra[kPredCols], rb[kPredCols], rc[kPredCols];
+#pragma unroll
+    for (int k = 0; k < kPredCols; k++) {
+        const int t = 3 + tid + k * nt;
+        if (t < N) {
+            const double* col = E.d_sigma + (size_t)t * ld;
+            ca[k] = col[0]; cb[k] = col[1]; cc[k] = col[2];
+            ra[k] = E.d_sigma[t]; rb[k] = E.d_sigma[(size_t)ld + t]; rc[k] = E.d_sigma[(size_t)2 * ld + t];
+        }
+    }
+    double S[9];
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) S[i * 3 + j] = E.d_sigma[(size_t)j * ld + i];
+    }
     if (tid == 0) {
         double delta_enl = dt * wl, delta_enr = dt * wr;
         double delta_sl = sp.kl * delta_enl, delta_sr = sp.kr * delta_enr;
@@ -76,26 +96,37 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
         double su0 = sp.Q_k * fabs(wl), su1 = sp.Q_k * fabs(wr);
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++) sQ[i * 3 + j] = wkh[i * 2] * su0 * wkh[j * 2] + wkh[i * 2 + 1] * su1 * wkh[j * 2 + 1];
-    }
-    __syncthreads();
-    for (int t = 3 + tid; t < N; t += nt) {
-        double* col = E.d_sigma + (size_t)t * ld;
-        const double a = col[0], b = col[1], c = col[2];
-        const double ra = E.d_sigma[t], rb = E.d_sigma[(size_t)ld + t], rc = E.d_sigma[(size_t)2 * ld + t];
-        col[0] = sH[0] * a + sH[1] * b + sH[2] * c;
-        col[1] = sH[3] * a + sH[4] * b + sH[5] * c;
-        col[2] = sH[6] * a + sH[7] * b + sH[8] * c;
-        E.d_sigma[t] = ra * sH[0] + rb * sH[1] + rc * sH[2];
-        E.d_sigma[(size_t)ld + t] = ra * sH[3] + rb * sH[4] + rc * sH[5];
-        E.d_sigma[(size_t)2 * ld + t] = ra * sH[6] + rb * sH[7] + rc * sH[8];
-    }
-    if (tid == 0) {
-        double S[9], T[9];
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) S[i * 3 + j] = E.d_sigma[(size_t)j * ld + i];
+        // pose block: H S H^T + Q (only thread 0 ever touches these nine entries)
+        double T[9];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[i * 3 + j] = sH[i * 3] * S[j] + sH[i * 3 + 1] * S[3 + j] + sH[i * 3 + 2] * S[6 + j];
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++)
                 E.d_sigma[(size_t)j * ld + i] = (T[i * 3] * sH[j * 3] + T[i * 3 + 1] * sH[j * 3 + 1] + T[i * 3 + 2] * sH[j * 3 + 2]) + sQ[i * 3 + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kPredCols; k++) {
+        const int t = 3 + tid + k * nt;
+        if (t < N) {
+            double* col = E.d_sigma + (size_t)t * ld;
+            col[0] = sH[0] * ca[k] + sH[1] * cb[k] + sH[2] * cc[k];
+            col[1] = sH[3] * ca[k] + sH[4] * cb[k] + sH[5] * cc[k];
+            col[2] = sH[6] * ca[k] + sH[7] * cb[k] + sH[8] * cc[k];
+            E.d_sigma[t] = ra[k] * sH[0] + rb[k] * sH[1] + rc[k] * sH[2];
+            E.d_sigma[(size_t)ld + t] = ra[k] * sH[3] + rb[k] * sH[4] + rc[k] * sH[5];
+            E.d_sigma[(size_t)2 * ld + t] = ra[k] * sH[6] + rb[k] * sH[7] + rc[k] * sH[8];
+        }
+    }
+    for (int t = 3 + tid + kPredCols * nt; t < N; t += nt) {         // larger maps: the remaining columns
+        double* col = E.d_sigma + (size_t)t * ld;
+        const double a = col[0], b = col[1], c = col[2];
+        const double xa = E.d_sigma[t], xb = E.d_sigma[(size_t)ld + t], xc = E.d_sigma[(size_t)2 * ld + t];
+        col[0] = sH[0] * a + sH[1] * b + sH[2] * c;
+        col[1] = sH[3] * a + sH[4] * b + sH[5] * c;
+        col[2] = sH[6] * a + sH[7] * b + sH[8] * c;
+        E.d_sigma[t] = xa * sH[0] + xb * sH[1] + xc * sH[2];
+        E.d_sigma[(size_t)ld + t] = xa * sH[3] + xb * sH[4] + xc * sH[5];
+        E.d_sigma[(size_t)2 * ld + t] = xa * sH[6] + xb * sH[7] + xc * sH[8];
     }
     __syncthreads();
 }
@@ -133,15 +164,15 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     LastObs myLast;
     if (tid < kMarkerMax) { myObs = obs[tid]; myLast = E.d_last[tid]; }          // slots beyond nM / nl are never used
     double mu0x = E.d_mu[0], mu0y = E.d_mu[1], mu0t = E.d_mu[2];
+    int myIndex = -2;                                                            // checkLandmark (aruco_slam.cpp:423-435), in flight during the predict
+    if (tid < nM && myObs.valid) myIndex = (myObs.id >= 0 && myObs.id < kIdTableSize) ? E.d_id2idx[myObs.id] : -1;
     if (do_predict) {
         predict_block(E, sp, wl, wr, dt, 3 + 3 * L0, sH, sQ, sMu);
         mu0x = sMu[0]; mu0y = sMu[1]; mu0t = sMu[2];                             // frozen pre-frame robot pose (Q1)
     }
     if (tid < nM) {
         sObs[tid] = myObs;
-        int index = -2;
-        if (myObs.valid) index = (myObs.id >= 0 && myObs.id < kIdTableSize) ? E.d_id2idx[myObs.id] : -1;   // checkLandmark (aruco_slam.cpp:423-435)
-        sIndex[tid] = index;
+        sIndex[tid] = myIndex;
     }
     if (tid < nl) sLast[tid] = myLast;
     if (tid == 0) { sNNew = 0; sNPop = 0; sDup = 0; }
