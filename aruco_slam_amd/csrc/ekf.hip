@@ -83,7 +83,8 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
         double delta_s = 0.5 * (delta_sr + delta_sl);
         const double m0 = E.d_mu[0], m1 = E.d_mu[1], m2 = E.d_mu[2];
         double tmp_th = m2 + 0.5 * delta_theta;
-        double c = cos(tmp_th), s = sin(tmp_th);
+        double c, s;
+        sincos(tmp_th, &s, &c);
         double th = m2 + delta_theta;
         wrap1(th);
         sMu[0] = m0 + delta_s * c; sMu[1] = m1 + delta_s * s; sMu[2] = th;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     __shared__ int sOrder[kMarkerMax];         // pop order
     __shared__ int sAction[kMarkerMax];        // per popped observation
     __shared__ int sUpdPos[kMarkerMax];        // position in the fused update list (-1 = none)
-    __shared__ int sNPop, sL, sM, sNNew, sDup;
+    __shared__ int sNPop, sL, sM, sNNew, sDup, sWaveCnt[2];
     __shared__ double sG[9], sMM[9], sNew[3];
     __shared__ int sDoAug;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -331,15 +332,19 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         sAction[q] = stationary ? 2 : 1;
     }
     __syncthreads();
-    if (tid == 0) {
-        int m = 0;
-        for (int q = 0; q < np; q++) sUpdPos[q] = (q >= nnew && sAction[q] == 1) ? m++ : -1;
-        if (m > max_m) {                 // more fused updates than the configured chain handles: reported, never silent
-            atomicOr(&ctr->overflow, (unsigned)kOvfUpdates);
-            for (int q = 0; q < np; q++) sUpdPos[q] = -1;
-            m = 0;
+    {
+        // position of every update in the fused list = number of updates popped before it (np <= kMarkerMax = 2 wavefronts)
+        const bool upd = tid < np && tid >= nnew && sAction[tid] == 1;
+        const unsigned long long bal = __ballot(upd);
+        if (tid < kMarkerMax && (tid & 63) == 0) sWaveCnt[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        const int before = (tid >= 64 ? sWaveCnt[0] : 0) + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        const int m = sWaveCnt[0] + sWaveCnt[1];
+        if (tid < np) sUpdPos[tid] = (upd && m <= max_m) ? before : -1;
+        if (tid == 0) {
+            if (m > max_m) atomicOr(&ctr->overflow, (unsigned)kOvfUpdates);   // more fused updates than the configured chain handles: reported, never silent
+            sM = m <= max_m ? m : 0;
         }
-        sM = m;
     }
     __syncthreads();
     for (int q = tid; q < np; q += nt) {
@@ -362,7 +367,8 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         if (up >= 0) {
             const int li = 3 + 3 * index;
             double mx = E.d_mu[li], my = E.d_mu[li + 1], mth = E.d_mu[li + 2];   // unchanged since frame start
-            double sintheta = sin(mu0t), costheta = cos(mu0t);
+            double sintheta, costheta;
+            sincos(mu0t, &sintheta, &costheta);
             double gdx = mx - mu0x, gdy = my - mu0y, gdth = mth - mu0t;
             wrap1(gdth);
             double zh0 = gdx * costheta + gdy * sintheta, zh1 = -gdx * sintheta + gdy * costheta;
