@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     __shared__ int sAction[kMarkerMax];        // per popped observation
     __shared__ int sUpdPos[kMarkerMax];        // position in the fused update list (-1 = none)
     __shared__ int sNPop, sL, sM, sNNew, sDup, sWaveCnt[2];
+    __shared__ double sLm[kMarkerMax][3];       // landmark mean per observation slot
     __shared__ double sG[9], sMM[9], sNew[3];
     __shared__ int sDoAug;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -167,6 +168,8 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     double mu0x = E.d_mu[0], mu0y = E.d_mu[1], mu0t = E.d_mu[2];
     int myIndex = -2;                                                            // checkLandmark (aruco_slam.cpp:423-435), in flight during the predict
     if (tid < nM && myObs.valid) myIndex = (myObs.id >= 0 && myObs.id < kIdTableSize) ? E.d_id2idx[myObs.id] : -1;
+    double lmx = 0, lmy = 0, lmt = 0;                                            // my landmark's mean (untouched by the predict)
+    if (myIndex >= 0) { const double* lm = E.d_mu + 3 + 3 * myIndex; lmx = lm[0]; lmy = lm[1]; lmt = lm[2]; }
     if (do_predict) {
         predict_block(E, sp, wl, wr, dt, 3 + 3 * L0, sH, sQ, sMu);
         mu0x = sMu[0]; mu0y = sMu[1]; mu0t = sMu[2];                             // frozen pre-frame robot pose (Q1)
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     if (tid < nM) {
         sObs[tid] = myObs;
         sIndex[tid] = myIndex;
+        sLm[tid][0] = lmx; sLm[tid][1] = lmy; sLm[tid][2] = lmt;
     }
     if (tid < nl) sLast[tid] = myLast;
     if (tid == 0) { sNNew = 0; sNPop = 0; sDup = 0; }
@@ -366,7 +370,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         const int up = sUpdPos[q];
         if (up >= 0) {
             const int li = 3 + 3 * index;
-            double mx = E.d_mu[li], my = E.d_mu[li + 1], mth = E.d_mu[li + 2];   // unchanged since frame start
+            const double mx = sLm[slot][0], my = sLm[slot][1], mth = sLm[slot][2];   // mu_[li..li+2], loaded at kernel start
             double sintheta, costheta;
             sincos(mu0t, &sintheta, &costheta);
             double gdx = mx - mu0x, gdy = my - mu0y, gdth = mth - mu0t;
