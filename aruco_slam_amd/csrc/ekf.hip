@@ -17,6 +17,8 @@
 
 namespace aslam {
 
+typedef double v4d __attribute__((vector_size(4 * sizeof(double))));   // accumulator of v_mfma_f64_16x16x4_f64
+
 __device__ __forceinline__ void wrap1(double& a) {      // ArucoSlam::normAngle (aruco_slam.cpp:412-421): wraps once
     const double PI = 3.14159265358979323846;
     if (a >= PI) a -= 2.0 * PI;
@@ -633,72 +635,63 @@ __global__ __launch_bounds__(768) void k_ekf_small(EkfState E) {
     }
 }
 
-// ---- T = G V (3m x N) and mu += W g : one workgroup per 64 columns, G and the V tile staged in LDS -----------
-constexpr int TKC = 32;                  // depth chunk of G / V staged per pass
+// ---- T = G V (3m x N) on the f64 matrix cores, and mu += W g -----------------------------------------------------
+// Workgroup (x, y) = 32 columns x 64 rows of T; wavefront w = 16 of those rows x 32 columns = two v_mfma_f64_16x16x4_f64
+// tiles.  Operands come straight from L2 in MFMA layout (A[i][k] = G[q0 + i][p0 + k] in lane k*16+i, B[k][j] = V[p0 + k][c0 + j]
+// in lane k*16+j): G is 3m x 3m (180 KB at m = 50) and V a 3m x 32 panel, both far below the cache sizes, and 94 x 3
+// workgroups cover the GPU where 47 scalar ones did not.  Workgroups with y = 0 also add W g to their 32 entries of mu.
+constexpr int TC = 32, TR = 64;
 
 __global__ __launch_bounds__(256) void k_ekf_T(EkfState E) {
-    __shared__ double sG[64][TKC + 1];           // G[q0 + qq][p0 + pp]   (64 output rows per pass)
-    __shared__ double sV[TKC][64];               // V[p0 + pp][c0 + x]
-    __shared__ double sMu[4][64];
+    __shared__ double sMu[8][TC];
     const int m = *E.d_m;
     const int n3 = 3 * m;
     const int N = 3 + 3 * (*E.d_L);
     const int ld = E.ld;
-    const int c0 = blockIdx.x * 64;
-    const int x = threadIdx.x & 63, qg = threadIdx.x >> 6;          // column in tile, group of 16 output rows
-    if (m > 0 && c0 < N) {                                           // uniform per workgroup
-        // mu += W g: 4 partial sums per column (strided over p), loads issued in bulk
-        {
-            double s = 0;
-            for (int p = qg; p < n3; p += 16) {
-                double w0 = (c0 + x < N) ? E.d_Wt[(size_t)p * ld + c0 + x] : 0.0, gg0 = E.d_g[p];
-                double w1 = (p + 4 < n3 && c0 + x < N) ? E.d_Wt[(size_t)(p + 4) * ld + c0 + x] : 0.0, gg1 = (p + 4 < n3) ? E.d_g[p + 4] : 0.0;
-                double w2 = (p + 8 < n3 && c0 + x < N) ? E.d_Wt[(size_t)(p + 8) * ld + c0 + x] : 0.0, gg2 = (p + 8 < n3) ? E.d_g[p + 8] : 0.0;
-                double w3 = (p + 12 < n3 && c0 + x < N) ? E.d_Wt[(size_t)(p + 12) * ld + c0 + x] : 0.0, gg3 = (p + 12 < n3) ? E.d_g[p + 12] : 0.0;
-                s += w0 * gg0 + w1 * gg1 + w2 * gg2 + w3 * gg3;
-            }
-            sMu[qg][x] = s;
+    const int c0 = blockIdx.x * TC, q0 = blockIdx.y * TR;
+    if (m <= 0 || c0 >= N || q0 >= n3) return;                      // uniform per workgroup
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    if (blockIdx.y == 0) {
+        // mu += W g: 8 partial sums per column (strided over p), combined in a fixed order
+        const int x = tid & 31, pg = tid >> 5;
+        double s = 0;
+        if (c0 + x < N)
+            for (int p = pg; p < n3; p += 8) s += E.d_Wt[(size_t)p * ld + c0 + x] * E.d_g[p];
+        sMu[pg][x] = s;
+    }
+    const int qrow = q0 + 16 * wave + li;                           // A operand row of this lane
+    const bool qok = qrow < n3;
+    const bool c0ok = c0 + li < N, c1ok = c0 + 16 + li < N;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const double* gp = E.d_G + (size_t)(qok ? qrow : 0) * n3;
+    // software pipeline: the operands of step p0 + 4 are in flight while step p0 multiplies
+    double a = (qok && lk < n3) ? gp[lk] : 0.0;
+    double b0 = (c0ok && lk < n3) ? E.d_V[(size_t)lk * ld + c0 + li] : 0.0;
+    double b1 = (c1ok && lk < n3) ? E.d_V[(size_t)lk * ld + c0 + 16 + li] : 0.0;
+    for (int p0 = 0; p0 < n3; p0 += 4) {
+        const int pn = p0 + 4 + lk;
+        const double an = (qok && pn < n3) ? gp[pn] : 0.0;
+        const double b0n = (c0ok && pn < n3) ? E.d_V[(size_t)pn * ld + c0 + li] : 0.0;
+        const double b1n = (c1ok && pn < n3) ? E.d_V[(size_t)pn * ld + c0 + 16 + li] : 0.0;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+        a = an; b0 = b0n; b1 = b1n;
+    }
+    // D rows (lane>>4) + 4*reg = row of T within the wave's 16, column lane&15
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int q = q0 + 16 * wave + lk + 4 * reg;
+        if (q < n3) {
+            if (c0ok) E.d_T[(size_t)q * ld + c0 + li] = acc0[reg];
+            if (c1ok) E.d_T[(size_t)q * ld + c0 + 16 + li] = acc1[reg];
         }
-        for (int q0 = 0; q0 < n3; q0 += 64) {
-            double acc[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) acc[j] = 0.0;
-            for (int p0 = 0; p0 < n3; p0 += TKC) {
-                double tg[8], tv[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {                        // all loads first
-                    const int i = threadIdx.x + 256 * k;
-                    const int qq = i / TKC, pp = i - qq * TKC;
-                    tg[k] = (q0 + qq < n3 && p0 + pp < n3) ? E.d_G[(size_t)(q0 + qq) * n3 + p0 + pp] : 0.0;
-                    const int vp = i >> 6, vx = i & 63;
-                    tv[k] = (p0 + vp < n3 && c0 + vx < N) ? E.d_V[(size_t)(p0 + vp) * ld + c0 + vx] : 0.0;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int i = threadIdx.x + 256 * k;
-                    const int qq = i / TKC, pp = i - qq * TKC;
-                    sG[qq][pp] = tg[k];
-                    sV[i >> 6][i & 63] = tv[k];
-                }
-                __syncthreads();
-                const int pe = min(TKC, n3 - p0);
-                for (int pp = 0; pp < pe; pp++) {
-                    const double v = sV[pp][x];
-#pragma unroll
-                    for (int j = 0; j < 16; j++) acc[j] += sG[qg * 16 + j][pp] * v;
-                }
-                __syncthreads();
-            }
-            if (c0 + x < N) {
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const int q = q0 + qg * 16 + j;
-                    if (q < n3) E.d_T[(size_t)q * ld + c0 + x] = acc[j];
-                }
-            }
-        }
-        if (qg == 0 && c0 + x < N)
-            E.d_mu[c0 + x] += (sMu[0][x] + sMu[1][x]) + (sMu[2][x] + sMu[3][x]);     // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
+    }
+    if (blockIdx.y == 0) {
+        __syncthreads();
+        if (tid < TC && c0 + tid < N)
+            E.d_mu[c0 + tid] += ((sMu[0][tid] + sMu[1][tid]) + (sMu[2][tid] + sMu[3][tid])) +
+                                ((sMu[4][tid] + sMu[5][tid]) + (sMu[6][tid] + sMu[7][tid]));   // mu_ += sum_i K_i ze_i (aruco_slam.cpp:203)
     }
 }
 
@@ -949,7 +942,6 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
 
 constexpr int APK = kFastN3;             // padded depth of the LDS images (72)
 
-typedef double v4d __attribute__((vector_size(4 * sizeof(double))));
 
 // f64 matrix cores (v_mfma_f64_16x16x4_f64) for both products of the tile.  Operand layout (cdna_hip_programming.md §3):
 // A[i][k] in lane k*16+i, B[k][j] in lane k*16+j, D rows (lane>>4)+4*reg, column lane&15.  The Sigma tile is formed
@@ -1247,57 +1239,67 @@ __global__ __launch_bounds__(1024) void k_ekf_mid64(EkfState E) {
 // register maps to 16 consecutive rows r of one column c: the read-modify-write of the column-major Sigma is coalesced.
 // Operand layout (cdna_hip_programming.md §3): A[i][k] in lane k*16+i, B[k][j] in lane k*16+j, D rows (lane>>4)+4*reg, col lane&15.
 
-constexpr int MUK = 16;                  // depth rows of T / W^T staged per chunk
+constexpr int MUK = 8;                   // depth rows of T / W^T staged per chunk
+constexpr int MUC = 128, MUR = 64;       // workgroup tile: MUC columns x MUR rows of Sigma, one wavefront per 64 columns
 
-__global__ __launch_bounds__(256) void k_ekf_update_mfma(EkfState E) {
-    __shared__ double sT[2][MUK][128];
-    __shared__ double sW[2][MUK][128];
+// Workgroup = 2 wavefronts, tile = 64 rows x 128 columns: at N = 3003 that is 47 x 24 = 1128 workgroups of 24 KB LDS, i.e. all
+// but a tenth of them resident at once on 256 CUs x 4 (the 128 x 128 tiles of a 4-wave workgroup left half of the second
+// round of workgroups empty).  The Sigma tile is loaded straight into the accumulators before the depth loop (its latency
+// hides behind the first chunks) and the product is subtracted by negating one operand: the epilogue is a pure store.
+__global__ __launch_bounds__(128) void k_ekf_update_mfma(EkfState E) {
+    __shared__ double sT[2][MUK][MUC];
+    __shared__ double sW[2][MUK][MUR];
     const int m = *E.d_m;
     if (m <= 0) return;
     const int n3 = 3 * m;
     const int N = 3 + 3 * (*E.d_L);
     const int ld = E.ld;
-    const int cb0 = blockIdx.y * 128, rb0 = blockIdx.x * 128;     // workgroup tile: columns cb0.., rows rb0.. of Sigma
+    const int cb0 = blockIdx.y * MUC, rb0 = blockIdx.x * MUR;     // workgroup tile: columns cb0.., rows rb0.. of Sigma
     if (cb0 >= N || rb0 >= N) return;                              // uniform per workgroup
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int wc = (wave >> 1) * 64, wr = (wave & 1) * 64;        // this wavefront's 64 x 64 sub-tile
+    const int wc = wave * 64;                                      // this wavefront's 64 columns (all 64 rows)
     const int li = lane & 15, lk = lane >> 4;
-    v4d acc[4][4];
+
+    // chunk loader: MUK x (128 + 64) doubles = 8 of T and 4 of W^T per thread, issued in bulk
+    const int wx = tid & 63, wp = tid >> 6;
+    double pt[MUK], pw[MUK / 2];
+    const int nchunks = (n3 + MUK - 1) / MUK;
+#pragma unroll
+    for (int k = 0; k < MUK; k++) pt[k] = (k < n3 && cb0 + tid < N) ? E.d_T[(size_t)k * ld + cb0 + tid] : 0.0;
+#pragma unroll
+    for (int k = 0; k < MUK / 2; k++) { const int p = wp + 2 * k; pw[k] = (p < n3 && rb0 + wx < N) ? E.d_Wt[(size_t)p * ld + rb0 + wx] : 0.0; }
+
+    v4d acc[4][4];                                                 // D'[c][r]: register reg of acc[ci][ri] = Sigma(r = 16 ri + li, c = 16 ci + lk + 4 reg)
 #pragma unroll
     for (int ci = 0; ci < 4; ci++)
 #pragma unroll
-        for (int ri = 0; ri < 4; ri++) acc[ci][ri] = v4d{0.0, 0.0, 0.0, 0.0};
-
-    // chunk loader: MUK x 128 doubles of T and of W^T = 8 + 8 values per thread, issued in bulk
-    const int lx = tid & 127, lp = tid >> 7;                      // column within the tile, depth row parity (0/1)
-    double pt[8], pw[8];
-    const int nchunks = (n3 + MUK - 1) / MUK;
+        for (int ri = 0; ri < 4; ri++)
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int p = lp + 2 * k;
-        pt[k] = (p < n3 && cb0 + lx < N) ? E.d_T[(size_t)p * ld + cb0 + lx] : 0.0;
-        pw[k] = (p < n3 && rb0 + lx < N) ? E.d_Wt[(size_t)p * ld + rb0 + lx] : 0.0;
-    }
+            for (int reg = 0; reg < 4; reg++) {
+                const int c = cb0 + wc + 16 * ci + lk + 4 * reg, r = rb0 + 16 * ri + li;
+                acc[ci][ri][reg] = (c < N && r < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
+            }
+
     for (int ch = 0; ch < nchunks; ch++) {
         const int buf = ch & 1;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { sT[buf][lp + 2 * k][lx] = pt[k]; sW[buf][lp + 2 * k][lx] = pw[k]; }
+        for (int k = 0; k < MUK; k++) sT[buf][k][tid] = pt[k];
+#pragma unroll
+        for (int k = 0; k < MUK / 2; k++) sW[buf][wp + 2 * k][wx] = pw[k];
         __syncthreads();
         if (ch + 1 < nchunks) {                                    // prefetch the next chunk while this one is multiplied
             const int pb = (ch + 1) * MUK;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int p = pb + lp + 2 * k;
-                pt[k] = (p < n3 && cb0 + lx < N) ? E.d_T[(size_t)p * ld + cb0 + lx] : 0.0;
-                pw[k] = (p < n3 && rb0 + lx < N) ? E.d_Wt[(size_t)p * ld + rb0 + lx] : 0.0;
-            }
+            for (int k = 0; k < MUK; k++) pt[k] = (pb + k < n3 && cb0 + tid < N) ? E.d_T[(size_t)(pb + k) * ld + cb0 + tid] : 0.0;
+#pragma unroll
+            for (int k = 0; k < MUK / 2; k++) { const int p = pb + wp + 2 * k; pw[k] = (p < n3 && rb0 + wx < N) ? E.d_Wt[(size_t)p * ld + rb0 + wx] : 0.0; }
         }
 #pragma unroll
         for (int kk = 0; kk < MUK / 4; kk++) {
             double a[4], b[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { a[q] = sT[buf][kk * 4 + lk][wc + 16 * q + li]; b[q] = sW[buf][kk * 4 + lk][wr + 16 * q + li]; }
+            for (int q = 0; q < 4; q++) { a[q] = -sT[buf][kk * 4 + lk][wc + 16 * q + li]; b[q] = sW[buf][kk * 4 + lk][16 * q + li]; }
 #pragma unroll
             for (int ci = 0; ci < 4; ci++)
 #pragma unroll
@@ -1311,8 +1313,8 @@ __global__ __launch_bounds__(256) void k_ekf_update_mfma(EkfState E) {
         for (int ri = 0; ri < 4; ri++)
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-                const int c = cb0 + wc + 16 * ci + lk + 4 * reg, r = rb0 + wr + 16 * ri + li;
-                if (c < N && r < N) E.d_sigma[(size_t)c * ld + r] -= acc[ci][ri][reg];
+                const int c = cb0 + wc + 16 * ci + lk + 4 * reg, r = rb0 + 16 * ri + li;
+                if (c < N && r < N) E.d_sigma[(size_t)c * ld + r] = acc[ci][ri][reg];
             }
 }
 
@@ -1402,7 +1404,7 @@ void launch_ekf_small(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_small, dim3(1), dim3(SMT), 0, st, E);
 }
 void launch_ekf_T(hipStream_t st, const EkfState& E) {
-    hipLaunchKernelGGL(k_ekf_T, dim3((E.ld + 63) / 64), dim3(256), 0, st, E);
+    hipLaunchKernelGGL(k_ekf_T, dim3((E.ld + TC - 1) / TC, (3 * kMarkerMax + TR - 1) / TR), dim3(256), 0, st, E);
 }
 void launch_ekf_update(hipStream_t st, const EkfState& E) {
     const int t = (E.ld + UT - 1) / UT;
@@ -1423,8 +1425,7 @@ void launch_ekf_mid64(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_mid64, dim3(1 + ncg * 16), dim3(1024), 0, st, E);
 }
 void launch_ekf_update_mfma(hipStream_t st, const EkfState& E) {
-    const int t = (E.ld + 127) / 128;
-    hipLaunchKernelGGL(k_ekf_update_mfma, dim3(t, t), dim3(256), 0, st, E);
+    hipLaunchKernelGGL(k_ekf_update_mfma, dim3((E.ld + MUR - 1) / MUR, (E.ld + MUC - 1) / MUC), dim3(128), 0, st, E);
 }
 void launch_ekf_export_map(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_export_map, dim3((E.max_landmarks + 255) / 256), dim3(256), 0, st, E);
