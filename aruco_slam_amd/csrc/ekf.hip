@@ -1061,9 +1061,13 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
 // =============================================================================================================
 constexpr int kMidM = 64;
 
-__global__ __launch_bounds__(1024) void k_ekf_mid64(EkfState E) {
-    __shared__ double sCol[2][kMidM][9];
-    __shared__ double sY[kMidM][9];
+constexpr int M64T = 512;                // threads of k_ekf_mid64: 8 wavefronts, 2 per SIMD -> 256 VGPRs each, no spills
+constexpr int M64B = (kMidM * kMidM + M64T - 1) / M64T;   // 3x3 blocks per thread (8)
+
+// The fast chain's Gauss-Jordan with up to M64B blocks per thread, dense block index e = tid + M64T k -> (e / m, e % m).
+__global__ __launch_bounds__(M64T) void k_ekf_mid64(EkfState E) {
+    __shared__ __align__(16) double sCol[2][kMidM][10];
+    __shared__ __align__(16) double sY[kMidM][10];
     __shared__ double sPinv[9];
     __shared__ double sZe[3 * kMidM], sNu[3 * kMidM];
     __shared__ double sPart[kMidM][kMidM][3];
@@ -1075,9 +1079,9 @@ __global__ __launch_bounds__(1024) void k_ekf_mid64(EkfState E) {
     if (blockIdx.x > 0) {
         // ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns) ----
         const int N = 3 + 3 * (*E.d_L);
-        const int ncg = (ld + 1023) / 1024;
+        const int ncg = (ld + M64T - 1) / M64T;
         const int gb = blockIdx.x - 1;
-        const int t = (gb % ncg) * 1024 + tid;
+        const int t = (gb % ncg) * M64T + tid;
         const int slice = gb / ncg, nslices = (gridDim.x - 1) / ncg;
         if (t < N) {
             const double* col = E.d_sigma + (size_t)t * ld;
@@ -1099,138 +1103,142 @@ __global__ __launch_bounds__(1024) void k_ekf_mid64(EkfState E) {
         }
         return;
     }
-    // ---- workgroup 0: thread (ti, tj) owns the blocks (ti + 32 ii, tj + 32 jj), ii, jj in {0, 1} ----
-    const int tj = tid & 31, ti = tid >> 5;
-    double A[2][2][9];
-    for (int r = tid; r < n3; r += 1024) { const double z = E.d_upd[r / 3].ze[r % 3]; sZe[r] = z; sNu[r] = z; }
+    // ---- workgroup 0: innovation matrix A = H Sigma0 H^T + R, 3x3 blocks in registers ----
+    const int nblk = m * m;
+    double A[M64B][9];
+    int bij[M64B];                                     // (bi << 8) | bj of this thread's blocks, -1 = none (the division is done once)
 #pragma unroll
-    for (int ii = 0; ii < 2; ii++)
+    for (int k = 0; k < M64B; k++) {
+        const int e = tid + M64T * k;
+        const int bi = e / m;
+        bij[k] = e < nblk ? ((bi << 8) | (e - bi * m)) : -1;
+    }
+    for (int r = tid; r < n3; r += M64T) { const double z = E.d_upd[r / 3].ze[r % 3]; sZe[r] = z; sNu[r] = z; }
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            const int bi = ti + 32 * ii, bj = tj + 32 * jj;
-            if (bi < m && bj < m) {
-                const UpdRec& ui = E.d_upd[bi];
-                const UpdRec& uj = E.d_upd[bj];
-                const int li = ui.li, lj = uj.li;
-                double S[36];
+    for (int k = 0; k < M64B; k++) {
+        if (bij[k] >= 0) {
+            const int bi = bij[k] >> 8, bj = bij[k] & 255;
+            const UpdRec& ui = E.d_upd[bi];
+            const UpdRec& uj = E.d_upd[bj];
+            const int li = ui.li, lj = uj.li;
+            double S[36];
 #pragma unroll
-                for (int p = 0; p < 6; p++)
+            for (int p = 0; p < 6; p++)
 #pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        const int r = p < 3 ? p : li + p - 3, c = q < 3 ? q : lj + q - 3;
-                        S[p * 6 + q] = E.d_sigma[(size_t)c * ld + r];
+                for (int q = 0; q < 6; q++) {
+                    const int r = p < 3 ? p : li + p - 3, c = q < 3 ? q : lj + q - 3;
+                    S[p * 6 + q] = E.d_sigma[(size_t)c * ld + r];
+                }
+            double HP[18];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    double acc = 0;
+#pragma unroll
+                    for (int p = 0; p < 6; p++) acc += ui.Gxm[a * 6 + p] * S[p * 6 + q];
+                    HP[a * 6 + q] = acc;
+                }
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double acc = 0;
+#pragma unroll
+                    for (int q = 0; q < 6; q++) acc += HP[a * 6 + q] * uj.Gxm[c * 6 + q];
+                    A[k][a * 3 + c] = acc;
+                }
+            if (bi == bj) { A[k][0] += ui.r[0]; A[k][4] += ui.r[1]; A[k][8] += ui.r[2]; }
+            if (bj == 0) { for (int q = 0; q < 9; q++) sCol[0][bi][q] = A[k][q]; }
+            if (bij[k] == 0) {
+                double Pn[9];
+                inv3_reg(A[k], Pn);
+                for (int q = 0; q < 9; q++) sPinv[q] = Pn[q];
+            }
+        }
+    }
+    __syncthreads();
+    // block Gauss-Jordan with 3x3 pivots (see k_ekf_mid)
+    for (int ib = 0; ib < m; ib++) {
+        const int cb = ib & 1;
+        // phase 1: the pivot row: Y_bj = S_ib^-1 * A(ib, bj)  (S_ib^-1 itself at bj == ib); the pivot column blocks are zeroed
+#pragma unroll
+        for (int k = 0; k < M64B; k++) {
+            if (bij[k] >= 0) {
+                const int bi = bij[k] >> 8, bj = bij[k] & 255;
+                if (bi == ib) {
+                    double Pi[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) Pi[q] = sPinv[q];
+                    if (bj == ib) {
+#pragma unroll
+                        for (int q = 0; q < 9; q++) A[k][q] = Pi[q];
+                    } else {
+                        double Y[9];
+                        mul3(Pi, A[k], Y);
+#pragma unroll
+                        for (int q = 0; q < 9; q++) A[k][q] = Y[q];
                     }
-                double HP[18];
 #pragma unroll
-                for (int a = 0; a < 3; a++)
+                    for (int q = 0; q < 9; q++) sY[bj][q] = A[k][q];
+                    if (bj == ib + 1) { for (int q = 0; q < 9; q++) sCol[cb ^ 1][bi][q] = A[k][q]; }
+                } else if (bj == ib) {
 #pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        double s = 0;
-#pragma unroll
-                        for (int p = 0; p < 6; p++) s += ui.Gxm[a * 6 + p] * S[p * 6 + q];
-                        HP[a * 6 + q] = s;
-                    }
-#pragma unroll
-                for (int a = 0; a < 3; a++)
-#pragma unroll
-                    for (int b = 0; b < 3; b++) {
-                        double s = 0;
-#pragma unroll
-                        for (int q = 0; q < 6; q++) s += HP[a * 6 + q] * uj.Gxm[b * 6 + q];
-                        A[ii][jj][a * 3 + b] = s;
-                    }
-                if (bi == bj) { A[ii][jj][0] += ui.r[0]; A[ii][jj][4] += ui.r[1]; A[ii][jj][8] += ui.r[2]; }
-                if (bj == 0) { for (int k = 0; k < 9; k++) sCol[0][bi][k] = A[ii][jj][k]; }
-                if (bi == 0 && bj == 0) {
-                    double Pn[9];
-                    inv3_reg(A[ii][jj], Pn);
-                    for (int k = 0; k < 9; k++) sPinv[k] = Pn[k];
+                    for (int q = 0; q < 9; q++) A[k][q] = 0.0;
                 }
             }
         }
-    __syncthreads();
-    for (int ib = 0; ib < m; ib++) {
-        const int cb = ib & 1;
-        // phase 1: the pivot row: Y_bj = S_ib^-1 * A(ib, bj)  (S_ib^-1 itself at bj == ib)
-#pragma unroll
-        for (int ii = 0; ii < 2; ii++)
-#pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
-                const int bi = ti + 32 * ii, bj = tj + 32 * jj;
-                if (bi == ib && bj < m) {
-                    double Pi[9];
-#pragma unroll
-                    for (int k = 0; k < 9; k++) Pi[k] = sPinv[k];
-                    if (bj == ib) {
-#pragma unroll
-                        for (int k = 0; k < 9; k++) A[ii][jj][k] = Pi[k];
-                    } else {
-                        double Y[9];
-                        mul3(Pi, A[ii][jj], Y);
-#pragma unroll
-                        for (int k = 0; k < 9; k++) A[ii][jj][k] = Y[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 9; k++) sY[bj][k] = A[ii][jj][k];
-                    if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[ii][jj][k]; }
-                }
-            }
         __syncthreads();
-        // phase 2: every other block: A(bi, bj) -= F * Y_bj with F = A(bi, ib) before this step
+        // phase 2: every other block: A(bi, bj) -= F * Y_bj, three fused multiply-adds per element
 #pragma unroll
-        for (int ii = 0; ii < 2; ii++)
+        for (int k = 0; k < M64B; k++) {
+            if (bij[k] >= 0) {
+                const int bi = bij[k] >> 8, bj = bij[k] & 255;
+                if (bi != ib) {
+                    double F[9], Y[9];
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
-                const int bi = ti + 32 * ii, bj = tj + 32 * jj;
-                if (bi < m && bj < m && bi != ib) {
-                    double F[9], Y[9], X[9];
+                    for (int q = 0; q < 9; q++) { F[q] = sCol[cb][bi][q]; Y[q] = sY[bj][q]; }
 #pragma unroll
-                    for (int k = 0; k < 9; k++) { F[k] = sCol[cb][bi][k]; Y[k] = sY[bj][k]; }
-                    mul3(F, Y, X);
-                    if (bj == ib) {
+                    for (int i = 0; i < 3; i++)
 #pragma unroll
-                        for (int k = 0; k < 9; k++) A[ii][jj][k] = -X[k];
-                        if (bi > ib) {
-                            const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
+                        for (int j = 0; j < 3; j++)
+                            A[k][i * 3 + j] = fma(-F[i * 3 + 2], Y[6 + j], fma(-F[i * 3 + 1], Y[3 + j], fma(-F[i * 3], Y[j], A[k][i * 3 + j])));
+                    if (bj == ib && bi > ib) {
+                        const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
 #pragma unroll
-                            for (int a = 0; a < 3; a++) sNu[3 * bi + a] += X[a * 3] * z0 + X[a * 3 + 1] * z1 + X[a * 3 + 2] * z2;
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 9; k++) A[ii][jj][k] -= X[k];
+                        for (int a = 0; a < 3; a++) sNu[3 * bi + a] -= A[k][a * 3] * z0 + A[k][a * 3 + 1] * z1 + A[k][a * 3 + 2] * z2;   // nu += (H K) ze, H K = -A
                     }
-                    if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[ii][jj][k]; }
+                    if (bj == ib + 1) { for (int q = 0; q < 9; q++) sCol[cb ^ 1][bi][q] = A[k][q]; }
                     if (bi == ib + 1 && bj == ib + 1) {
                         double Pn[9];
-                        inv3_reg(A[ii][jj], Pn);
+                        inv3_reg(A[k], Pn);
 #pragma unroll
-                        for (int k = 0; k < 9; k++) sPinv[k] = Pn[k];
+                        for (int q = 0; q < 9; q++) sPinv[q] = Pn[q];
                     }
                 }
             }
+        }
         __syncthreads();
     }
 #pragma unroll
-    for (int ii = 0; ii < 2; ii++)
+    for (int k = 0; k < M64B; k++) {
+        if (bij[k] >= 0) {
+            const int bi = bij[k] >> 8, bj = bij[k] & 255;
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-            const int bi = ti + 32 * ii, bj = tj + 32 * jj;
-            if (bi < m && bj < m) {
+            for (int a = 0; a < 3; a++)
 #pragma unroll
-                for (int a = 0; a < 3; a++)
+                for (int c = 0; c < 3; c++) E.d_G[(size_t)(3 * bi + a) * n3 + 3 * bj + c] = A[k][a * 3 + c];
+            const double n0 = sNu[3 * bj], n1 = sNu[3 * bj + 1], n2 = sNu[3 * bj + 2];
 #pragma unroll
-                    for (int b = 0; b < 3; b++) E.d_G[(size_t)(3 * bi + a) * n3 + 3 * bj + b] = A[ii][jj][a * 3 + b];
-                const double n0 = sNu[3 * bj], n1 = sNu[3 * bj + 1], n2 = sNu[3 * bj + 2];
-#pragma unroll
-                for (int a = 0; a < 3; a++) sPart[bi][bj][a] = A[ii][jj][a * 3] * n0 + A[ii][jj][a * 3 + 1] * n1 + A[ii][jj][a * 3 + 2] * n2;
-            }
+            for (int a = 0; a < 3; a++) sPart[bi][bj][a] = A[k][a * 3] * n0 + A[k][a * 3 + 1] * n1 + A[k][a * 3 + 2] * n2;
         }
+    }
     __syncthreads();
-    for (int r = tid; r < n3; r += 1024) {
+    for (int r = tid; r < n3; r += M64T) {
         const int i = r / 3, a = r - 3 * i;
-        double s = 0;
-        for (int j = 0; j < m; j++) s += sPart[i][j][a];
-        E.d_g[r] = s;
+        double acc = 0;
+        for (int j = 0; j < m; j++) acc += sPart[i][j][a];
+        E.d_g[r] = acc;
     }
 }
 
@@ -1421,8 +1429,8 @@ void launch_ekf_apply(hipStream_t st, const EkfState& E) {
 int ekf_fast_max_updates() { return kFastM; }
 int ekf_mid_max_updates() { return kMidM; }
 void launch_ekf_mid64(hipStream_t st, const EkfState& E) {
-    const int ncg = (E.ld + 1023) / 1024;
-    hipLaunchKernelGGL(k_ekf_mid64, dim3(1 + ncg * 16), dim3(1024), 0, st, E);
+    const int ncg = (E.ld + M64T - 1) / M64T;
+    hipLaunchKernelGGL(k_ekf_mid64, dim3(1 + ncg * 16), dim3(M64T), 0, st, E);
 }
 void launch_ekf_update_mfma(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_update_mfma, dim3((E.ld + MUR - 1) / MUR, (E.ld + MUC - 1) / MUC), dim3(128), 0, st, E);
