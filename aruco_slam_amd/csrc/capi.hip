@@ -84,6 +84,7 @@ struct aslam_ctx {
     SynthMarker* d_synth = nullptr;
     size_t in_frame_bytes = 0, pitch = 0;
     int dict_ms = 5, dict_n = 1024, dict_maxcorr = 0;
+    float* d_refine_mask = nullptr;       // cornerSubPix window weights (15 x 15 at most)
     aslam_detector_params dp{};           // cv::aruco::DetectorParameters in force (defaults of 3.2.0 unless aslam_set_detector_params)
     std::vector<unsigned long long> dict_cells;   // per id: (ms+2)^2 cell image incl. border (for the renderer)
 
@@ -291,7 +292,10 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
         prof_end(c);
         prof_begin(c, P_POSE, st);
         launch_pose(st, nf, c->d_finals + (size_t)f0 * kCandMax, c->d_nfinal + f0, c->d_markers + (size_t)f0 * kMarkerMax,
-                    c->d_nmarkers + f0, c->d_obs + (size_t)f0 * kMarkerMax, c->cam, c->sp, c->d_ctr);
+                    c->d_nmarkers + f0, c->d_obs + (size_t)f0 * kMarkerMax, c->cam, c->sp, c->d_ctr,
+                    RefineCfg{c->dp.doCornerRefinement ? 1 : 0, c->dp.cornerRefinementWinSize, std::min(std::max(c->dp.cornerRefinementMaxIterations, 1), 100),
+                              g.rows, g.cols, std::max(c->dp.cornerRefinementMinAccuracy, 0.0) * std::max(c->dp.cornerRefinementMinAccuracy, 0.0),
+                              c->d_refine_mask, gray});
         prof_end(c);
     }
     HIP_TRY(c, hipEventRecord(c->ev_detect, st));
@@ -457,6 +461,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && dalloc(&c->d_ckpt, ((size_t)c->init.cap_points_per_frame / kCkptStride + c->init.cap_contours_per_frame) * B) == hipSuccess;
     ok = ok && dalloc(&c->d_nckpt, B) == hipSuccess;
     ok = ok && dalloc(&c->d_lane_ckpt, (size_t)c->nwaves * 64 * ((size_t)(4.0 * std::max(init->max_rows, init->max_cols)) / kCkptStride + 2)) == hipSuccess;
+    ok = ok && dalloc(&c->d_refine_mask, 15 * 15) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_write, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_trace, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_quads, (size_t)max_frames_per_call() + 1) == hipSuccess;
@@ -496,6 +501,7 @@ void aslam_destroy(aslam_ctx* c) {
     if (c->stream_ekf) hipStreamSynchronize(c->stream_ekf);
     prof_collect(c);
     hipFree(c->d_in); hipFree(c->d_gray); hipFree(c->d_nbr); hipFree(c->d_starts); hipFree(c->d_ctr);
+    hipFree(c->d_refine_mask);
     hipFree(c->d_ckpt); hipFree(c->d_nckpt); hipFree(c->d_lane_ckpt); hipFree(c->d_pre_write);
     hipFree(c->d_nstarts); hipFree(c->d_ncontours); hipFree(c->d_npoints); hipFree(c->d_pre_trace); hipFree(c->d_pre_quads);
     hipFree(c->d_contours); hipFree(c->d_points); hipFree(c->d_cands); hipFree(c->d_ncand); hipFree(c->d_finals);
@@ -704,7 +710,9 @@ int aslam_set_detector_params(aslam_ctx* c, const aslam_detector_params* p) {
         return fail(c, ASLAM_E_INVALID, "adaptiveThreshWinSize{Min,Max,Step} are compiled in as 3/23/10");
     if (p->perspectiveRemovePixelPerCell != kCellPx) return fail(c, ASLAM_E_INVALID, "perspectiveRemovePixelPerCell is compiled in as 8");
     if (p->markerBorderBits != 1) return fail(c, ASLAM_E_INVALID, "markerBorderBits is compiled in as 1");
-    if (p->doCornerRefinement) return fail(c, ASLAM_E_INVALID, "corner refinement is not built (off in the reference)");
+    if (p->doCornerRefinement && (p->cornerRefinementWinSize < 1 || p->cornerRefinementWinSize > 7 || p->cornerRefinementMaxIterations < 1 ||
+                                  !(p->cornerRefinementMinAccuracy > 0)))
+        return fail(c, ASLAM_E_INVALID, "corner refinement: window 1..7, at least one iteration, positive accuracy");
     if (!(p->maxMarkerPerimeterRate > 0 && p->maxMarkerPerimeterRate <= 4.0) || !(p->minMarkerPerimeterRate > 0) ||
         p->minMarkerPerimeterRate > p->maxMarkerPerimeterRate)
         return fail(c, ASLAM_E_INVALID, "0 < minMarkerPerimeterRate <= maxMarkerPerimeterRate <= 4");
@@ -715,6 +723,20 @@ int aslam_set_detector_params(aslam_ctx* c, const aslam_detector_params* p) {
     int r = sync_streams(c);
     if (r) return r;
     c->dp = *p;
+    if (p->doCornerRefinement) {
+        // cornerSubPix's separable window (cornersubpix.cpp): float arithmetic on the host, the same libm as the CPU restatement
+        const int win = p->cornerRefinementWinSize, w = 2 * win + 1;
+        std::vector<float> mask((size_t)w * w);
+        for (int i = 0; i < w; i++) {
+            float y = (float)(i - win) / win;
+            float vy = std::exp(-y * y);
+            for (int j = 0; j < w; j++) {
+                float x = (float)(j - win) / win;
+                mask[(size_t)i * w + j] = (float)(vy * std::exp(-x * x));
+            }
+        }
+        HIP_TRY(c, hipMemcpy(c->d_refine_mask, mask.data(), mask.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     if (c->rows > 0) return configure_frames(c, c->rows, c->cols, c->channels);
     return ASLAM_OK;
 }

@@ -306,9 +306,85 @@ __device__ int point_in_quad(const float* q, float px, float py) {
     return counter % 2 == 0 ? -1 : 1;
 }
 
+// ---- cv::cornerSubPix (imgproc/cornersubpix.cpp, 3.2.0) for one corner, one lane -------------------------------------
+// Optional stage (DetectorParameters::doCornerRefinement, off in the reference).  The (win+2)^2 patch that OpenCV samples
+// into a buffer with getRectSubPix is evaluated on the fly, element by element with the same float expressions (interior
+// fast path: dst[j] = prev + t, prev = (float)(t * (1-a)/a); clipped path: four-tap bilinear with replicated borders), and
+// the normal equations are accumulated in the same order, so the result is bit-identical to the scalar restatement.
+struct SubPix {
+    const uint8_t* gray;
+    int rows, cols, ipx, ipy;
+    bool interior;
+    float a, b, a11, a12, a21, a22, b1, b2;
+    double s;
+};
+__device__ __forceinline__ float subpix_at(const SubPix& P, int i, int j) {         // element (row i, column j) of the patch
+    if (P.interior) {
+        const uint8_t* p = P.gray + (size_t)(P.ipy + i) * P.cols + P.ipx;
+        const float t = P.a12 * p[j + 1] + P.a22 * p[j + 1 + P.cols];
+        float prev;
+        if (j == 0) prev = (1 - P.a) * (P.b1 * p[0] + P.b2 * p[P.cols]);
+        else { const float tp = P.a12 * p[j] + P.a22 * p[j + P.cols]; prev = (float)(tp * P.s); }
+        return prev + t;
+    }
+    const int y0 = min(max(P.ipy + i, 0), P.rows - 1), y1 = min(max(P.ipy + i + 1, 0), P.rows - 1);
+    const int x0 = min(max(P.ipx + j, 0), P.cols - 1), x1 = min(max(P.ipx + j + 1, 0), P.cols - 1);
+    return P.gray[(size_t)y0 * P.cols + x0] * P.a11 + P.gray[(size_t)y0 * P.cols + x1] * P.a12 + P.gray[(size_t)y1 * P.cols + x0] * P.a21 +
+           P.gray[(size_t)y1 * P.cols + x1] * P.a22;
+}
+__device__ void corner_sub_pix_one(const uint8_t* gray, int rows, int cols, const float* __restrict__ mask, int win, int max_iters,
+                                   double eps2, float& x, float& y) {
+    const int win_w = 2 * win + 1, pw = win_w + 2;
+    const float cTx = x, cTy = y;
+    float cIx = x, cIy = y;
+    int iter = 0;
+    double err = 0;
+    do {
+        SubPix P;
+        P.gray = gray; P.rows = rows; P.cols = cols;
+        const float centerx = cIx - (pw - 1) * 0.5f, centery = cIy - (pw - 1) * 0.5f;
+        P.ipx = (int)floorf(centerx); P.ipy = (int)floorf(centery);
+        P.interior = 0 <= P.ipx && P.ipx + pw < cols && 0 <= P.ipy && P.ipy + pw < rows;
+        P.a = centerx - P.ipx; P.b = centery - P.ipy;
+        if (P.interior) {
+            P.a = P.a > 0.0001f ? P.a : 0.0001f;
+            P.a12 = P.a * (1.f - P.b); P.a22 = P.a * P.b; P.b1 = 1.f - P.b; P.b2 = P.b;
+            P.s = (1. - P.a) / P.a;
+            P.a11 = P.a21 = 0.f;
+        } else {
+            P.a11 = (1.f - P.a) * (1.f - P.b); P.a12 = P.a * (1.f - P.b); P.a21 = (1.f - P.a) * P.b; P.a22 = P.a * P.b;
+            P.b1 = P.b2 = 0.f; P.s = 0.0;
+        }
+        double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+        for (int i = 0, k = 0; i < win_w; i++) {
+            const double py = i - win;
+            for (int j = 0; j < win_w; j++, k++) {
+                const double m = mask[k];
+                const double tgx = subpix_at(P, i + 1, j + 2) - subpix_at(P, i + 1, j);
+                const double tgy = subpix_at(P, i + 2, j + 1) - subpix_at(P, i, j + 1);
+                const double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                const double px = j - win;
+                a += gxx; b += gxy; c += gyy;
+                bb1 += gxx * px + gxy * py;
+                bb2 += gxy * px + gyy * py;
+            }
+        }
+        const double det = a * c - b * b;
+        if (fabs(det) <= DBL_EPSILON * DBL_EPSILON) break;
+        const double scale = 1.0 / det;
+        const float nx = (float)(cIx + c * scale * bb1 - b * scale * bb2);
+        const float ny = (float)(cIy - b * scale * bb1 + a * scale * bb2);
+        err = (nx - cIx) * (nx - cIx) + (ny - cIy) * (ny - cIy);
+        cIx = nx; cIy = ny;
+        if (cIx < 0 || cIx >= cols || cIy < 0 || cIy >= rows) break;
+    } while (++iter < max_iters && err > eps2);
+    if (fabsf(cIx - cTx) > win || fabsf(cIy - cTy) > win) { cIx = cTx; cIy = cTy; }      // poor convergence: keep the initial point
+    x = cIx; y = cIy;
+}
+
 __global__ __launch_bounds__(128) void k_pose(const FinalCand* __restrict__ finals, const unsigned* __restrict__ n_final,
                                               Marker* __restrict__ markers, unsigned* __restrict__ n_markers,
-                                              ObsRaw* __restrict__ obs, CamParams cam, SlamParams sp, Counters* ctr) {
+                                              ObsRaw* __restrict__ obs, CamParams cam, SlamParams sp, Counters* ctr, RefineCfg rf) {
     __shared__ float sC[kMarkerMax][8];
     __shared__ int sId[kMarkerMax];
     __shared__ unsigned char sRem[kMarkerMax];
@@ -368,6 +444,14 @@ __global__ __launch_bounds__(128) void k_pose(const FinalCand* __restrict__ fina
     }
     __syncthreads();
     const int M = sM;
+    if (rf.on) {                                               // uniform: cornerSubPix on the surviving markers, one lane per corner
+        const uint8_t* gray = rf.gray + (size_t)f * rf.rows * rf.cols;
+        for (int e = tid; e < 4 * M; e += 128) {
+            const int i = sOut[e >> 2], q = e & 3;
+            corner_sub_pix_one(gray, rf.rows, rf.cols, rf.mask, rf.win, rf.max_iters, rf.eps2, sC[i][2 * q], sC[i][2 * q + 1]);
+        }
+        __syncthreads();
+    }
     for (int k = tid; k < M; k += 128) {
         const int i = sOut[k];
         Marker mk;
@@ -414,8 +498,8 @@ __global__ __launch_bounds__(128) void k_pose(const FinalCand* __restrict__ fina
 }
 
 void launch_pose(hipStream_t st, int nframes, const FinalCand* finals, const unsigned* n_final, Marker* markers,
-                 unsigned* n_markers, ObsRaw* obs, const CamParams& cam, const SlamParams& sp, Counters* ctr) {
-    hipLaunchKernelGGL(k_pose, dim3(nframes), dim3(128), 0, st, finals, n_final, markers, n_markers, obs, cam, sp, ctr);
+                 unsigned* n_markers, ObsRaw* obs, const CamParams& cam, const SlamParams& sp, Counters* ctr, const RefineCfg& rf) {
+    hipLaunchKernelGGL(k_pose, dim3(nframes), dim3(128), 0, st, finals, n_final, markers, n_markers, obs, cam, sp, ctr, rf);
 }
 
 } // namespace aslam

@@ -22,7 +22,7 @@ Camera make_cam(const double K[9], const double* D, int nD) {
 }
 Dictionary& dict() { static Dictionary d = make_dict_aruco_original(); return d; }
 DetectorParams& params() { static DetectorParams p; return p; }
-// 17 values in the order of struct DetectorParams (oracle.h); NULL = the OpenCV 3.2.0 defaults
+// 20 values in the order of struct DetectorParams (oracle.h); NULL = the OpenCV 3.2.0 defaults
 DetectorParams params_from(const double* v) {
     DetectorParams p;
     if (!v) return p;
@@ -32,6 +32,8 @@ DetectorParams params_from(const double* v) {
     p.minMarkerDistanceRate = v[9]; p.markerBorderBits = (int)v[10]; p.perspectiveRemovePixelPerCell = (int)v[11];
     p.perspectiveRemoveIgnoredMarginPerCell = v[12]; p.maxErroneousBitsInBorderRate = v[13]; p.minOtsuStdDev = v[14];
     p.errorCorrectionRate = v[15];
+    p.doCornerRefinement = v[16] != 0; p.cornerRefinementWinSize = (int)v[17]; p.cornerRefinementMaxIterations = (int)v[18];
+    p.cornerRefinementMinAccuracy = v[19];
     return p;
 }
 }
@@ -180,6 +182,12 @@ void* orc_slam_create(const double params[10], float useful_distance_threshold, 
 }
 void orc_slam_destroy(void* h) { delete static_cast<SlamHandle*>(h); }
 void orc_slam_set_camera(void* h, const double K[9], const double* D, int nD) { static_cast<SlamHandle*>(h)->slam.setCamera(make_cam(K, D, nD)); }
+void orc_corner_sub_pix(const uint8_t* gray, int rows, int cols, float* corners_xy, int count, int win, int max_iter, double eps) {
+    std::vector<Pt2f> c(count);
+    for (int i = 0; i < count; i++) c[i] = Pt2f{corners_xy[2 * i], corners_xy[2 * i + 1]};
+    corner_sub_pix(gray, rows, cols, c.data(), count, win, max_iter, eps);
+    for (int i = 0; i < count; i++) { corners_xy[2 * i] = c[i].x; corners_xy[2 * i + 1] = c[i].y; }
+}
 void orc_set_detector_params(const double* v) { params() = params_from(v); }
 void orc_slam_set_detector_params(void* h, const double* v) { static_cast<SlamHandle*>(h)->slam.dp = params_from(v); }
 void orc_slam_set_dictionary(void* h, int ms, int n, int maxcorr, const uint8_t* bits) {

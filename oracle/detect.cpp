@@ -671,6 +671,97 @@ void detect_markers(const uint8_t* img, int rows, int cols, int channels, size_t
         }
     }
     filter_detected_markers(out);
+    // aruco.cpp::detectMarkers: "if (params->doCornerRefinement)" -> cornerSubPix on the grey image, per marker, after filtering
+    if (P.doCornerRefinement)
+        for (Detection& d : out)
+            corner_sub_pix(gray.data(), rows, cols, d.c, 4, P.cornerRefinementWinSize, P.cornerRefinementMaxIterations, P.cornerRefinementMinAccuracy);
+}
+
+// imgproc/samplers.cpp::getRectSubPix for CV_8UC1 -> CV_32FC1 (3.2.0): bilinear patch of win_w x win_h centred on `center`.
+// Interior fast path: dst[j] = prev + t with prev carried as (float)(t * (1-a)/a); otherwise the generic path on a rectangle
+// clipped to the image with replicated borders.
+void get_rect_sub_pix_8u32f(const uint8_t* src, int rows, int cols, int win_w, int win_h, float cx, float cy, float* dst) {
+    float centerx = cx - (win_w - 1) * 0.5f, centery = cy - (win_h - 1) * 0.5f;
+    int ipx = (int)std::floor(centerx), ipy = (int)std::floor(centery);
+    if (0 <= ipx && ipx + win_w < cols && 0 <= ipy && ipy + win_h < rows) {
+        float a = centerx - ipx, b = centery - ipy;
+        a = a > 0.0001f ? a : 0.0001f;
+        float a12 = a * (1.f - b), a22 = a * b, b1 = 1.f - b, b2 = b;
+        double s = (1. - a) / a;
+        const uint8_t* p = src + (size_t)ipy * cols + ipx;
+        for (int i = 0; i < win_h; i++, p += cols, dst += win_w) {
+            float prev = (1 - a) * (b1 * p[0] + b2 * p[cols]);
+            for (int j = 0; j < win_w; j++) {
+                float t = a12 * p[j + 1] + a22 * p[j + 1 + cols];
+                dst[j] = prev + t;
+                prev = (float)(t * s);
+            }
+        }
+        return;
+    }
+    // getRectSubPix_Cn_<uchar, float, float, nop, nop> with adjustRect: replicate the border
+    float a = centerx - ipx, b = centery - ipy;
+    float a11 = (1.f - a) * (1.f - b), a12 = a * (1.f - b), a21 = (1.f - a) * b, a22 = a * b;
+    for (int i = 0; i < win_h; i++)
+        for (int j = 0; j < win_w; j++) {
+            int y0 = std::min(std::max(ipy + i, 0), rows - 1), y1 = std::min(std::max(ipy + i + 1, 0), rows - 1);
+            int x0 = std::min(std::max(ipx + j, 0), cols - 1), x1 = std::min(std::max(ipx + j + 1, 0), cols - 1);
+            dst[i * win_w + j] = src[(size_t)y0 * cols + x0] * a11 + src[(size_t)y0 * cols + x1] * a12 + src[(size_t)y1 * cols + x0] * a21 +
+                                 src[(size_t)y1 * cols + x1] * a22;
+        }
+}
+
+// imgproc/cornersubpix.cpp::cornerSubPix (3.2.0), zeroZone = (-1,-1), criteria = MAX_ITER | EPS
+void corner_sub_pix(const uint8_t* gray, int rows, int cols, Pt2f* corners, int count, int win, int maxCount, double epsilon) {
+    const int MAX_ITERS = 100;
+    const int win_w = win * 2 + 1, win_h = win * 2 + 1;
+    const int max_iters = std::min(std::max(maxCount, 1), MAX_ITERS);
+    double eps = std::max(epsilon, 0.);
+    eps *= eps;
+    std::vector<float> mask((size_t)win_w * win_h), buf((size_t)(win_w + 2) * (win_h + 2));
+    for (int i = 0; i < win_h; i++) {
+        float y = (float)(i - win) / win;
+        float vy = std::exp(-y * y);
+        for (int j = 0; j < win_w; j++) {
+            float x = (float)(j - win) / win;
+            mask[i * win_w + j] = (float)(vy * std::exp(-x * x));
+        }
+    }
+    for (int pt = 0; pt < count; pt++) {
+        const Pt2f cT = corners[pt];
+        Pt2f cI = cT;
+        int iter = 0;
+        double err = 0;
+        do {
+            Pt2f cI2;
+            double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
+            get_rect_sub_pix_8u32f(gray, rows, cols, win_w + 2, win_h + 2, cI.x, cI.y, buf.data());
+            const float* subpix = &buf[(size_t)(win_w + 2) + 1];
+            for (int i = 0, k = 0; i < win_h; i++, subpix += win_w + 2) {
+                double py = i - win;
+                for (int j = 0; j < win_w; j++, k++) {
+                    double m = mask[k];
+                    double tgx = subpix[j + 1] - subpix[j - 1];
+                    double tgy = subpix[j + win_w + 2] - subpix[j - win_w - 2];
+                    double gxx = tgx * tgx * m, gxy = tgx * tgy * m, gyy = tgy * tgy * m;
+                    double px = j - win;
+                    a += gxx; b += gxy; c += gyy;
+                    bb1 += gxx * px + gxy * py;
+                    bb2 += gxy * px + gyy * py;
+                }
+            }
+            double det = a * c - b * b;
+            if (std::fabs(det) <= DBL_EPSILON * DBL_EPSILON) break;
+            double scale = 1.0 / det;
+            cI2.x = (float)(cI.x + c * scale * bb1 - b * scale * bb2);
+            cI2.y = (float)(cI.y - b * scale * bb1 + a * scale * bb2);
+            err = (cI2.x - cI.x) * (cI2.x - cI.x) + (cI2.y - cI.y) * (cI2.y - cI.y);
+            cI = cI2;
+            if (cI.x < 0 || cI.x >= cols || cI.y < 0 || cI.y >= rows) break;
+        } while (++iter < max_iters && err > eps);
+        if (std::fabs(cI.x - cT.x) > win || std::fabs(cI.y - cT.y) > win) cI = cT;     // poor convergence: keep the initial point
+        corners[pt] = cI;
+    }
 }
 
 } // namespace oracle

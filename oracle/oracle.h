@@ -46,6 +46,10 @@ struct DetectorParams {
     double maxErroneousBitsInBorderRate = 0.35;
     double minOtsuStdDev              = 5.0;
     double errorCorrectionRate        = 0.6;
+    bool   doCornerRefinement         = false;  // off in the reference (default parameters)
+    int    cornerRefinementWinSize    = 5;
+    int    cornerRefinementMaxIterations = 30;
+    double cornerRefinementMinAccuracy = 0.1;
 };
 
 struct Pt  { int x, y; };
@@ -97,6 +101,8 @@ int  otsu_threshold(const uint8_t* img, int n);
 void extract_bits(const uint8_t* gray, int rows, int cols, const Pt2f corners[4], int markerSize,
                   const DetectorParams& p, std::vector<uint8_t>& bits);
 Dictionary make_dict_aruco_original();
+void get_rect_sub_pix_8u32f(const uint8_t* src, int rows, int cols, int win_w, int win_h, float cx, float cy, float* dst);
+void corner_sub_pix(const uint8_t* gray, int rows, int cols, Pt2f* corners, int count, int win, int maxCount, double epsilon);
 Dictionary make_dict_from_bits(int markerSize, int nMarkers, int maxCorrectionBits, const uint8_t* bits);
 bool dictionary_identify(const Dictionary& d, const uint8_t* onlyBits, int& idx, int& rotation, double rate);
 bool identify_one_candidate(const Dictionary& d, const uint8_t* gray, int rows, int cols, Pt2f corners[4],

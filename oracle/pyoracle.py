@@ -39,6 +39,7 @@ def load():
         L.orc_slam_set_dictionary.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_set_dictionary.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_set_detector_params.argtypes = [_dp]
+        L.orc_corner_sub_pix.argtypes = [_u8p, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_double]
         L.orc_slam_set_detector_params.argtypes = [C.c_void_p, _dp]
         L.orc_slam_add_image.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_size_t]
         L.orc_slam_add_poses.argtypes = [C.c_void_p, C.c_int, _ip, _fp, _dp, _dp]
@@ -152,8 +153,9 @@ def detect(img, maxn=1024):
 PARAM_ORDER = ("adaptiveThreshWinSizeMin", "adaptiveThreshWinSizeMax", "adaptiveThreshWinSizeStep", "adaptiveThreshConstant",
                "minMarkerPerimeterRate", "maxMarkerPerimeterRate", "polygonalApproxAccuracyRate", "minCornerDistanceRate",
                "minDistanceToBorder", "minMarkerDistanceRate", "markerBorderBits", "perspectiveRemovePixelPerCell",
-               "perspectiveRemoveIgnoredMarginPerCell", "maxErroneousBitsInBorderRate", "minOtsuStdDev", "errorCorrectionRate")
-PARAM_DEFAULTS = (3, 23, 10, 7.0, 0.03, 4.0, 0.05, 0.05, 3, 0.05, 1, 8, 0.13, 0.35, 5.0, 0.6)
+               "perspectiveRemoveIgnoredMarginPerCell", "maxErroneousBitsInBorderRate", "minOtsuStdDev", "errorCorrectionRate",
+               "doCornerRefinement", "cornerRefinementWinSize", "cornerRefinementMaxIterations", "cornerRefinementMinAccuracy")
+PARAM_DEFAULTS = (3, 23, 10, 7.0, 0.03, 4.0, 0.05, 0.05, 3, 0.05, 1, 8, 0.13, 0.35, 5.0, 0.6, 0, 5, 30, 0.1)
 
 
 def _param_vector(kw):
@@ -169,6 +171,13 @@ def set_detector_params(**kw):
     """cv::aruco::DetectorParameters for the free functions; no arguments = OpenCV 3.2.0 defaults"""
     v = _param_vector(kw)
     load().orc_set_detector_params(_p(v, _dp))
+
+
+def corner_sub_pix(gray, corners, win=5, max_iter=30, eps=0.1):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    c = np.ascontiguousarray(corners, np.float32).reshape(-1, 2).copy()
+    load().orc_corner_sub_pix(_p(gray, _u8p), gray.shape[0], gray.shape[1], _p(c, _fp), int(c.shape[0]), int(win), int(max_iter), float(eps))
+    return c
 
 
 def set_dictionary(bits, max_correction_bits=0):

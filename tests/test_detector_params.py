@@ -52,7 +52,7 @@ def test_parameters_change_the_result():
 
 
 @pytest.mark.parametrize("bad", [dict(adaptiveThreshWinSizeMax=33), dict(perspectiveRemovePixelPerCell=4), dict(markerBorderBits=2),
-                                 dict(doCornerRefinement=1), dict(maxMarkerPerimeterRate=6.0), dict(polygonalApproxAccuracyRate=0.0)])
+                                 dict(doCornerRefinement=1, cornerRefinementWinSize=9), dict(maxMarkerPerimeterRate=6.0), dict(polygonalApproxAccuracyRate=0.0)])
 def test_compiled_in_or_invalid_values_are_refused(bad):
     ctx = capi.Context(max_rows=64, max_cols=64, max_batch=1, persistent_waves=4, max_landmarks=16)
     with pytest.raises(capi.AslamError):
@@ -68,3 +68,57 @@ def test_non_default_parameters_full_frame(alt_params):
     ctx.run_staged(0, 1, with_ekf=False)
     ctx.sync()
     pc.check_stages(ctx, 0, img, expect_ids=ids, perim_rates=(0.08, 3.0), thresh_c=9.5)
+
+
+@pytest.fixture
+def refine_params():
+    kw = dict(doCornerRefinement=1, cornerRefinementWinSize=5, cornerRefinementMaxIterations=30, cornerRefinementMinAccuracy=0.1)
+    orc.set_detector_params(**kw)
+    yield kw
+    orc.set_detector_params()
+
+
+def _refined(ctx, rows, cols, K, ids, poses, kw, seed, bgr=False):
+    gray = ctx.synth_render(0, rows, cols, K, ids, poses, noise_amp=2, seed=seed)
+    ctx.run_staged(0, 1, with_ekf=False); ctx.sync()
+    plain = ctx.get_slot_detections(0)
+    ctx.set_detector_params(**kw)
+    if bgr:
+        img = np.stack([gray, gray, gray], -1)
+        ctx.stage_frames(img)
+        gray = orc.bgr2gray(img)
+    ctx.run_staged(0, 1, with_ekf=False); ctx.sync()
+    got, corners, rv, tv = pc.check_stages(ctx, 0, gray, expect_ids=ids)       # final corners compared bit for bit with the oracle's
+    assert np.array_equal(np.sort(plain[0]), np.sort(got))
+    assert np.abs(corners - np.round(corners)).max() > 1e-3                   # no longer on the pixel grid
+    order = [list(plain[0]).index(i) for i in got]
+    assert np.abs(corners - plain[1][order]).max() < 5.0                       # within the search window
+    return got, corners, rv, tv
+
+
+def test_corner_refinement_matches_oracle(refine_params):
+    rows, cols = 240, 320
+    ctx, ids, poses, K = _scene(rows, cols, 300.0, 3, 1, (0.9, 1.4))
+    got, corners, rv, tv = _refined(ctx, rows, cols, K, ids, poses, refine_params, 5)
+    pc.check_poses(got, corners, rv, tv, K, np.zeros(5))
+
+
+def test_corner_refinement_near_the_image_border(refine_params):
+    """a marker a few pixels from the frame edge: the sampling window leaves the image (clipped / replicated path)"""
+    rows, cols = 200, 260
+    K = synth.camera_matrix(rows, cols, 260.0)
+    R, t = synth.marker_pose((-0.296, -0.192, 0.9), 0.1)
+    poses = np.concatenate([R.reshape(-1), t])[None, :]
+    ids = np.array([77], np.int32)
+    ctx = capi.Context(max_rows=rows, max_cols=cols, max_batch=1, persistent_waves=4, max_landmarks=16)
+    ctx.set_camera(K, np.zeros(5))
+    got, corners, rv, tv = _refined(ctx, rows, cols, K, ids, poses, refine_params, 2, bgr=True)
+    assert corners.min() < 9.0                                                  # really next to the border
+
+
+@pytest.mark.gpu
+def test_corner_refinement_full_frame(refine_params):
+    rows, cols = 720, 1280
+    ctx, ids, poses, K = _scene(rows, cols, 900.0, 20, 3, (1.9, 2.6))
+    got, corners, rv, tv = _refined(ctx, rows, cols, K, ids, poses, refine_params, 7)
+    pc.check_poses(got, corners, rv, tv, K, np.zeros(5))

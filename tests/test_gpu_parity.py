@@ -192,3 +192,29 @@ def test_cfg5_detect_batch_64_frames():
         assert sorted(ids_o.tolist()) == expect[i]
         if i % 8 == 0:
             pc.check_poses(ids_o, c_o, rv_g[i, :n], tv_g[i, :n], K, D)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_scenes_against_oracle(seed):
+    """frame sizes off the tile grid, bgr / gray input, lens distortion, noise levels, marker counts: ids, corners, poses"""
+    rng = np.random.RandomState(100 + seed)
+    rows = int(rng.choice([360, 480, 601, 720]))
+    cols = int(rng.choice([487, 640, 853, 1280]))
+    f = 0.7 * cols
+    n = int(rng.randint(1, 9))
+    ids, poses, K = synth.simple_scene(rows, cols, f, n, seed=seed, tz=(1.0, 2.4), max_yaw_deg=40.0)
+    D = np.zeros(5) if seed % 2 == 0 else np.array([-0.12, 0.06, 0.001, -0.0015, 0.0])
+    ctx = capi.Context(max_rows=rows, max_cols=cols, max_batch=1, max_landmarks=16)
+    ctx.set_camera(K, D)
+    gray = ctx.synth_render(0, rows, cols, K, ids, poses, noise_amp=int(rng.randint(0, 7)), seed=seed,
+                            background=int(rng.choice([90, 128, 200])))
+    if seed % 3 == 0:
+        img = np.stack([gray, gray, gray], -1)
+        img[..., 0] = np.roll(gray, 2, 0)                      # channels differ so that the grey conversion matters
+        ctx.stage_frames(img)
+        gray = orc.bgr2gray(img)
+    ctx.run_staged(0, 1, with_ekf=False)
+    ctx.sync()
+    got, corners, rv, tv = pc.check_stages(ctx, 0, gray)
+    if len(got):
+        pc.check_poses(got, corners, rv, tv, K, D)
