@@ -218,3 +218,33 @@ def test_randomised_scenes_against_oracle(seed):
     got, corners, rv, tv = pc.check_stages(ctx, 0, gray)
     if len(got):
         pc.check_poses(got, corners, rv, tv, K, D)
+
+
+def test_alternating_detection_only_and_full_calls_share_slots_safely():
+    """detection-only calls run on the whole GPU, calls with an EKF chain on the CU-masked stream: switching between them on
+    the same slots must serialise correctly (events), whatever is still in flight"""
+    cfg = synth.CONFIGS["cfg2"]
+    w = synth.PanelWorld(cfg)
+    n = 24
+    frs = [w.frame(i) for i in range(n)]
+    a = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=n, max_landmarks=w.L + 8)
+    b = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=n, max_landmarks=w.L + 8)
+    for c in (a, b):
+        c.set_camera(w.K, np.zeros(5))
+        for i, fr in enumerate(frs):
+            c.synth_render(i, cfg.rows, cfg.cols, w.K, fr.ids, fr.poses, noise_amp=2, seed=i, download=False)
+        c.stage_encoders([f.wl for f in frs], [f.wr for f in frs], [f.dt for f in frs])
+    a.run_staged(0, n, with_ekf=True); a.sync()                 # reference: one full call
+    # b: the same work cut into pieces that hop between the two detection streams without any host synchronisation
+    b.run_staged(0, n, with_ekf=False)
+    b.run_staged(0, 8, with_ekf=True)
+    b.run_staged(8, 16, with_ekf=False)
+    b.run_staged(8, 8, with_ekf=True)
+    b.run_staged(0, 4, with_ekf=False)                          # overlaps slots whose EKF steps may still be running
+    b.run_staged(16, 8, with_ekf=True)
+    b.sync()
+    mu_a, S_a = a.get_state(); mu_b, S_b = b.get_state()
+    assert np.array_equal(mu_a, mu_b) and np.array_equal(S_a, S_b)
+    for i in (0, 3, 9, 23):
+        da, db = a.get_slot_detections(i), b.get_slot_detections(i)
+        assert all(np.array_equal(x, y) for x, y in zip(da, db))
