@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                                                    size_t in_row_step, uint8_t* __restrict__ gray_out,
                                                    uint8_t* __restrict__ nbr, DetectCfg cfg,
                                                    unsigned* __restrict__ starts, unsigned* __restrict__ n_starts,
-                                                   Counters* ctr) {
+                                                   Counters* ctr, int nframes) {
     __shared__ uint8_t g[LH][LW];
     __shared__ unsigned I[LH + 1][LW + 1];
     __shared__ uint8_t bin[TH + 2][TW + 2];
@@ -50,9 +50,17 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
     __shared__ unsigned sNStart, sBase;
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    // XCD-aware tile order: consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Give every
+    // XCD one contiguous run of tiles (raster order inside a frame, frames in sequence) so that the 12-px halo a tile shares
+    // with its neighbours is re-read from the SAME L2 instead of being fetched from HBM once per XCD.
     const int rows = cfg.rows, cols = cfg.cols;
+    const unsigned gx = (unsigned)(cols + TW - 1) / TW, gy = (unsigned)(rows + TH - 1) / TH;
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= gx * gy * (unsigned)nframes) return;            // padding of the grid to a multiple of 8
+    const int b = (int)(logical / (gx * gy));
+    const unsigned rem = logical - (unsigned)b * gx * gy;
+    const int x0 = (int)(rem % gx) * TW, y0 = (int)(rem / gx) * TH;
     const uint8_t* src = in + (size_t)b * in_frame_stride;
     if (tid == 0) sNStart = 0;
 
@@ -1013,8 +1021,9 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
 // ------------------------------------------------------------------------------------------------
 void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t frame_stride, size_t row_step, int nframes,
                       uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, Counters* ctr) {
-    dim3 grid((cfg.cols + TW - 1) / TW, (cfg.rows + TH - 1) / TH, nframes);
-    hipLaunchKernelGGL(k_threshold, grid, dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg, starts, n_starts, ctr);
+    const unsigned total = (unsigned)((cfg.cols + TW - 1) / TW) * (unsigned)((cfg.rows + TH - 1) / TH) * (unsigned)nframes;
+    hipLaunchKernelGGL(k_threshold, dim3((total + 7u) / 8u * 8u), dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg, starts,
+                       n_starts, ctr, nframes);
 }
 void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre) {
     hipLaunchKernelGGL(k_prefix, dim3(1), dim3(256), 0, st, nframes, counts, cap, per_ticket, pre);
