@@ -788,8 +788,22 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
     __shared__ double sZe[kFastN3], sNu[kFastN3];
     __shared__ double sPart[kFastM][kFastM][3];
     const int tid = threadIdx.x;
+    // workgroup 0 stages the first kFastM update records in LDS with loads issued TOGETHER with the load of m (they do not
+    // depend on it; records past m are stale and never used): one global round trip less on the dependent chain
+    constexpr int kUpdDoubles = (int)(sizeof(UpdRec) / sizeof(double));
+    __shared__ double sUpdRaw[kFastM * kUpdDoubles];
+    double u0 = 0.0, u1 = 0.0;
+    if (blockIdx.x == 0) {
+        const double* raw = reinterpret_cast<const double*>(E.d_upd);
+        u0 = raw[tid];
+        if (tid + MIDT < kFastM * kUpdDoubles) u1 = raw[tid + MIDT];
+    }
     const int m = *E.d_m;
     const int ld = E.ld;
+    if (blockIdx.x == 0) {
+        sUpdRaw[tid] = u0;
+        if (tid + MIDT < kFastM * kUpdDoubles) sUpdRaw[tid + MIDT] = u1;
+    }
     if (m <= 0 || m > kFastM) return;                  // uniform (m > kFastM is reported by k_ekf_plan)
     const int n3 = 3 * m;
     if (blockIdx.x > 0) {
@@ -823,10 +837,12 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
     const int bj = tid % m, bi = tid / m;              // dense m x m mapping: the active threads fill whole waves
     const bool act = bi < m && bj < m;
     double A[9];
-    if (tid < n3) { const double z = E.d_upd[tid / 3].ze[tid % 3]; sZe[tid] = z; sNu[tid] = z; }
+    __syncthreads();                                   // sUpdRaw complete
+    const UpdRec* sUpd = reinterpret_cast<const UpdRec*>(sUpdRaw);
+    if (tid < n3) { const double z = sUpd[tid / 3].ze[tid % 3]; sZe[tid] = z; sNu[tid] = z; }
     if (act) {
-        const UpdRec& ui = E.d_upd[bi];
-        const UpdRec& uj = E.d_upd[bj];
+        const UpdRec& ui = sUpd[bi];
+        const UpdRec& uj = sUpd[bj];
         const int li = ui.li, lj = uj.li;
         // the 6x6 block Sigma0[c6_i, c6_j] (c6 = robot triple + landmark triple), every load issued before the first use
         double S[36];
@@ -926,7 +942,7 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int b = 0; b < 3; b++) E.d_G[(size_t)(3 * bi + a) * n3 + 3 * bj + b] = A[a * 3 + b];
+            for (int b = 0; b < 3; b++) E.d_G[(size_t)(3 * bi + a) * kFastN3 + 3 * bj + b] = A[a * 3 + b];   // fixed row stride (k_ekf_apply loads before it knows m)
         const double n0 = sNu[3 * bj], n1 = sNu[3 * bj + 1], n2 = sNu[3 * bj + 2];
 #pragma unroll
         for (int a = 0; a < 3; a++) sPart[bi][bj][a] = A[a * 3] * n0 + A[a * 3 + 1] * n1 + A[a * 3 + 2] * n2;
@@ -952,13 +968,8 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
     __shared__ double sVW[APK][64];           // V tile, later the W^T tile
     __shared__ double sT[APK + 8][64];        // T tile = G V tile (rows 72..79 belong to the padded 5th q-tile)
     __shared__ double sg[APK];
-    const int m = *E.d_m;
-    if (m <= 0 || m > kFastM) return;         // uniform
-    const int n3 = 3 * m;
-    const int N = 3 + 3 * (*E.d_L);
     const int ld = E.ld;
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    if (r0 >= N || c0 >= N) return;           // uniform
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -972,35 +983,53 @@ __global__ __launch_bounds__(256) void k_ekf_apply(EkfState E) {
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
-            sig[ri][reg] = (r < N && c < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
+            sig[ri][reg] = (r < ld && c < ld) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
         }
+    // None of these addresses depends on m or N (G has the fixed row stride APK, V / W^T rows the stride ld), so they are all
+    // in flight together with the loads of m and L; what lies beyond n3 / N is stale and is masked when it is staged.
     constexpr int NG = (APK * APK + 255) / 256;      // 21
     constexpr int NV = APK * 64 / 256;               // 18
     double tg[NG], tv[NV], tw[NV];
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         const int i = tid + 256 * k;
-        const int q = i / APK, pq = i - q * APK;
-        tg[k] = (i < APK * APK && q < n3 && pq < n3) ? E.d_G[(size_t)q * n3 + pq] : 0.0;
+        tg[k] = (i < APK * APK) ? E.d_G[i] : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < NV; k++) {
         const int i = tid + 256 * k;
         const int pq = i >> 6, xx = i & 63;
-        tv[k] = (pq < n3 && c0 + xx < N) ? E.d_V[(size_t)pq * ld + c0 + xx] : 0.0;
-        tw[k] = (pq < n3 && r0 + xx < N) ? E.d_Wt[(size_t)pq * ld + r0 + xx] : 0.0;
+        tv[k] = (c0 + xx < ld) ? E.d_V[(size_t)pq * ld + c0 + xx] : 0.0;
+        tw[k] = (r0 + xx < ld) ? E.d_Wt[(size_t)pq * ld + r0 + xx] : 0.0;
     }
-    const double gval = (tid < APK && tid < n3) ? E.d_g[tid] : 0.0;
+    const double graw = (tid < APK) ? E.d_g[tid] : 0.0;
+    const int m = *E.d_m;
+    const int N = 3 + 3 * (*E.d_L);
+    if (m <= 0 || m > kFastM || r0 >= N || c0 >= N) return;     // uniform
+    const int n3 = 3 * m;
+#pragma unroll
+    for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
+            if (!(r < N && c < N)) sig[ri][reg] = 0.0;
+        }
 #pragma unroll
     for (int k = 0; k < NG; k++) {
         const int i = tid + 256 * k;
         const int q = i / APK, pq = i - q * APK;
-        if (i < APK * APK) sGt[pq * APK + q] = tg[k];
+        if (i < APK * APK) sGt[pq * APK + q] = (q < n3 && pq < n3) ? tg[k] : 0.0;
     }
     if (tid < 16) sGt[APK * APK + tid] = 0.0;
 #pragma unroll
-    for (int k = 0; k < NV; k++) { const int i = tid + 256 * k; sVW[i >> 6][i & 63] = tv[k]; }
-    if (tid < APK) sg[tid] = gval;
+    for (int k = 0; k < NV; k++) {
+        const int i = tid + 256 * k;
+        const int pq = i >> 6, xx = i & 63;
+        if (!(pq < n3 && c0 + xx < N)) tv[k] = 0.0;
+        if (!(pq < n3 && r0 + xx < N)) tw[k] = 0.0;
+        sVW[pq][xx] = tv[k];
+    }
+    if (tid < APK) sg[tid] = tid < n3 ? graw : 0.0;
     __syncthreads();
 
     // T tile (80 x 64, rows >= 72 unused): wave w owns columns 16w .. 16w+15 and all five 16-row tiles
