@@ -355,8 +355,8 @@ int sync_streams(aslam_ctx* c) {
 }
 
 int install_dictionary(aslam_ctx* c, int ms, int n, int maxcorr, const uint8_t* bits) {
-    if (ms < 3 || ms + 2 > kDictMaxCells || n < 1 || n > (1 << 16) || maxcorr < 0 || !bits)
-        return fail(c, ASLAM_E_INVALID, "dictionary: marker size 3..7, 1..65536 markers, maxCorrectionBits >= 0");
+    if (ms < 3 || ms + 2 > kDictMaxCells || n < 1 || n > kIdTableSize || maxcorr < 0 || !bits)
+        return fail(c, ASLAM_E_INVALID, "dictionary: marker size 3..7, 1..1024 markers (the id -> landmark table), maxCorrectionBits >= 0");
     std::vector<unsigned long long> codes;
     make_dict_from_bits(ms, n, bits, codes, c->dict_cells);
     int r = sync_streams(c);
