@@ -783,8 +783,8 @@ __device__ __forceinline__ void mul3(const double* X, const double* Y, double* Z
 // <= 128 VGPRs (4 waves per SIMD) so that the workgroup always finds room beside the persistent detection waves of the other stream
 __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
     __shared__ __align__(16) double sCol[2][kFastM][10];   // pivot column blocks (bi, ib); rows padded to 80 B for 128-bit LDS reads
-    __shared__ __align__(16) double sY[kFastM][10];                  // S_ib^-1 * pivot row blocks of the current step
-    __shared__ double sPinv[9];                       // S_ib^-1 of the current step (formed at the end of the previous one)
+    __shared__ __align__(16) double sRow[2][kFastM][10];   // pivot row blocks (ib, bj), unscaled
+    __shared__ __align__(16) double sPinv[2][10];          // S_ib^-1 (from the owner of the pivot block, one step ahead)
     __shared__ double sZe[kFastN3], sNu[kFastN3];
     __shared__ double sPart[kFastM][kFastM][3];
     const int tid = threadIdx.x;
@@ -878,61 +878,64 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
             }
         if (bi == bj) { A[0] += ui.r[0]; A[4] += ui.r[1]; A[8] += ui.r[2]; }
         if (bj == 0) { for (int k = 0; k < 9; k++) sCol[0][bi][k] = A[k]; }
+        if (bi == 0) { for (int k = 0; k < 9; k++) sRow[0][bj][k] = A[k]; }
         if (bi == 0 && bj == 0) {
             double Pn[9];
             inv3_reg(A, Pn);
-            for (int k = 0; k < 9; k++) sPinv[k] = Pn[k];
+            for (int k = 0; k < 9; k++) sPinv[0][k] = Pn[k];
         }
     }
     __syncthreads();
-    // block Gauss-Jordan with 3x3 pivots: pivot block ib IS S_ib = H_ib Sigma_{ib-1} H_ib^T + R_ib, and the block multiplier
-    // F S_ib^-1 of a later row block IS H_bi K_ib (the reference's own recursion, aruco_slam.cpp:146,204)
+    // Block Gauss-Jordan with 3x3 pivots: pivot block ib IS S_ib = H_ib Sigma_{ib-1} H_ib^T + R_ib, and the block multiplier
+    // F S_ib^-1 of a later row block IS H_bi K_ib (the reference's own recursion, aruco_slam.cpp:146,204).
+    // One barrier per step: a step publishes the NEXT pivot's row blocks R_bj = A(ib+1, bj), column blocks F_bi = A(bi, ib+1)
+    // and inverse (from the block's owner); in the next step every thread scales its own column's row block itself,
+    // Y_bj = S^-1 R_bj (27 flops, redundant down each column) instead of waiting for the pivot row to do it.
     for (int ib = 0; ib < m; ib++) {
         const int cb = ib & 1;
-        // phase 1: the pivot row (m threads): Y_bj = S_ib^-1 * A(ib, bj)  (S_ib^-1 itself at bj == ib) -> their new blocks
-        if (act && bi == ib) {
-            double Pi[9];
+        if (act) {
+            double Pi[9], Y[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) Pi[k] = sPinv[k];
+            for (int k = 0; k < 9; k++) Pi[k] = sPinv[cb][k];
             if (bj == ib) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) A[k] = Pi[k];
+                for (int k = 0; k < 9; k++) Y[k] = Pi[k];                    // pivot column: Y is S^-1 itself
             } else {
-                double Y[9];
-                mul3(Pi, A, Y);
+                double R[9];
 #pragma unroll
-                for (int k = 0; k < 9; k++) A[k] = Y[k];
+                for (int k = 0; k < 9; k++) R[k] = sRow[cb][bj][k];
+                mul3(Pi, R, Y);
             }
+            if (bi == ib) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) sY[bj][k] = A[k];
-            if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[k]; }     // next step's F of this row
-        } else if (act && bj == ib) {
+                for (int k = 0; k < 9; k++) A[k] = Y[k];                     // pivot row: S^-1 A(ib, bj), S^-1 on the diagonal
+            } else {
+                double F[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) A[k] = 0.0;                                            // pivot column: becomes 0 - F * S^-1
-        }
-        __syncthreads();
-        // phase 2: every other block: A(bi, bj) -= F * Y_bj with F = A(bi, ib) before this step (0 - F * S^-1 at bj == ib:
-        // those blocks were zeroed during phase 1), as three fused multiply-adds per element
-        if (act && bi != ib) {
-            double F[9], Y[9];
+                for (int k = 0; k < 9; k++) F[k] = sCol[cb][bi][k];
+                if (bj == ib) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) { F[k] = sCol[cb][bi][k]; Y[k] = sY[bj][k]; }
+                    for (int k = 0; k < 9; k++) A[k] = 0.0;                  // pivot column: becomes 0 - F S^-1
+                }
 #pragma unroll
-            for (int i = 0; i < 3; i++)
+                for (int i = 0; i < 3; i++)
 #pragma unroll
-                for (int j = 0; j < 3; j++)
-                    A[i * 3 + j] = fma(-F[i * 3 + 2], Y[6 + j], fma(-F[i * 3 + 1], Y[3 + j], fma(-F[i * 3], Y[j], A[i * 3 + j])));
-            if (bj == ib && bi > ib) {
-                const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
+                    for (int j = 0; j < 3; j++)
+                        A[i * 3 + j] = fma(-F[i * 3 + 2], Y[6 + j], fma(-F[i * 3 + 1], Y[3 + j], fma(-F[i * 3], Y[j], A[i * 3 + j])));
+                if (bj == ib && bi > ib) {
+                    const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
 #pragma unroll
-                for (int a = 0; a < 3; a++) sNu[3 * bi + a] -= A[a * 3] * z0 + A[a * 3 + 1] * z1 + A[a * 3 + 2] * z2;   // nu += (H K) ze, H K = -A
+                    for (int a = 0; a < 3; a++) sNu[3 * bi + a] -= A[a * 3] * z0 + A[a * 3 + 1] * z1 + A[a * 3 + 2] * z2;   // nu += (H K) ze, H K = -A
+                }
             }
+            // what step ib + 1 needs
+            if (bi == ib + 1) { for (int k = 0; k < 9; k++) sRow[cb ^ 1][bj][k] = A[k]; }
             if (bj == ib + 1) { for (int k = 0; k < 9; k++) sCol[cb ^ 1][bi][k] = A[k]; }
-            if (bi == ib + 1 && bj == ib + 1) {                  // next pivot block S_{ib+1}: invert it now
+            if (bi == ib + 1 && bj == ib + 1) {
                 double Pn[9];
                 inv3_reg(A, Pn);
 #pragma unroll
-                for (int k = 0; k < 9; k++) sPinv[k] = Pn[k];
+                for (int k = 0; k < 9; k++) sPinv[cb ^ 1][k] = Pn[k];
             }
         }
         __syncthreads();
