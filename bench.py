@@ -164,6 +164,8 @@ def main():
     try:
         import glob
         pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))["kernels"].get(dominant)
+        if args.config != "cfg2":
+            pmc = None                                        # the PMC passes are runs of the default (cfg2) command
         if pmc:
             scale = 1.0 if dominant.startswith("k_ekf") else (args.steps * B / launches) / 200.0
             traffic = int((pmc.get("FETCH_SIZE_KB_per_launch", 0) + pmc.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 * scale)
