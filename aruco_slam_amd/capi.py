@@ -90,6 +90,7 @@ _SIGS = {
     "aslam_get_pose_msg": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aslam_get_map_markers": (C.c_int, [C.c_void_p, C.c_int, _ip, C.c_void_p]),
     "aslam_get_detected_markers": (C.c_int, [C.c_void_p, C.c_int, _ip, C.c_void_p]),
+    "aslam_load_map_txt": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_void_p]),
     "aslam_save_state": (C.c_int, [C.c_void_p, C.c_char_p]),
     "aslam_load_state": (C.c_int, [C.c_void_p, C.c_char_p]),
     "aslam_stream_open": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -220,6 +221,14 @@ class Context:
 
     def detected_markers(self):
         return self._markers(self.lib.aslam_get_detected_markers)
+
+    def load_map_txt(self, path):
+        n = C.c_int(0)
+        self._ck(self.lib.aslam_load_map_txt(self.h, str(path).encode(), 0, C.byref(n), None))
+        arr = (MarkerMsg * max(n.value, 1))()
+        self._ck(self.lib.aslam_load_map_txt(self.h, str(path).encode(), n.value, C.byref(n), arr))
+        return [dict(id=a.id, scale=tuple(a.scale), color=tuple(a.color), position=np.array(a.position), orientation=np.array(a.orientation),
+                     lifetime=a.lifetime_sec) for a in arr[:n.value]]
 
     def save_state(self, path):
         self._ck(self.lib.aslam_save_state(self.h, str(path).encode()))

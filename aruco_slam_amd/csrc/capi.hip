@@ -9,6 +9,9 @@
 #include <string>
 #include <vector>
 #include <cfloat>
+#include <fstream>
+#include <sstream>
+#include <cctype>
 #include <cstdio>
 #include <cstring>
 #include <cstdio>
@@ -956,6 +959,45 @@ int aslam_get_detected_markers(aslam_ctx* c, int max, int* n, aslam_marker_msg* 
         k++;
     }
     *n = k;
+    return ASLAM_OK;
+}
+
+// MapLoader::loadMap (map_loader.cpp:7-81) as plain data: the ground-truth map file behind the latched `real_map` topic.
+// One marker per line "id length x y [z [roll [pitch [yaw]]]]"; '#' starts a comment line, blank lines are skipped, a line
+// that starts with anything else than a digit aborts the whole load with an EMPTY result; a line with fewer than four
+// fields is skipped.  The optional fields reproduce the loader's crossed fallbacks: a missing roll zeroes YAW, a missing yaw
+// zeroes ROLL (each leaving the other at whatever the previous line left there; 0 at the start).  Orientation =
+// setRPY(roll, pitch, yaw); CUBE (length, length, 0.01), rgba (1, 1, 1, 0.5), frame "world", lifetime 0
+// (MapLoader::generateMarker, map_loader.cpp:96-118).  Needs no device: ctx may be NULL.
+int aslam_load_map_txt(aslam_ctx* c, const char* path, int max, int* n, aslam_marker_msg* out) {
+    if (!path || !n) return c ? fail(c, ASLAM_E_INVALID, "null argument") : ASLAM_E_INVALID;
+    *n = 0;
+    std::ifstream f(path);
+    if (!f.good()) return c ? fail(c, ASLAM_E_INVALID, std::string("cannot read ") + path) : ASLAM_E_INVALID;
+    std::string line;
+    int count = 0;
+    int id = 0;
+    double length = 0, x = 0, y = 0, z = 0, yaw = 0, pitch = 0, roll = 0;       // deliberately outside the loop: see above
+    while (std::getline(f, line)) {
+        std::istringstream s(line);
+        char first = 0;
+        if (!(s >> first)) continue;                          // blank line
+        if (first == '#') continue;
+        if (!isdigit((unsigned char)first)) { *n = 0; return ASLAM_OK; }       // "Malformed input": the map is cleared
+        s.putback(first);
+        if (!(s >> id >> length >> x >> y)) continue;
+        if (!(s >> z)) z = 0;
+        if (!(s >> roll)) yaw = 0;
+        if (!(s >> pitch)) pitch = 0;
+        if (!(s >> yaw)) roll = 0;
+        if (out && count < max) {
+            double q[4];
+            quat_from_rpy(roll, pitch, yaw, q);
+            fill_marker(out[count], id, length, x, y, z, q, 1.f, 1.f, 1.f, 0.5f, 0.0);
+        }
+        count++;
+    }
+    *n = count;
     return ASLAM_OK;
 }
 

@@ -157,6 +157,11 @@ int aslam_get_pose_msg(aslam_ctx* ctx, aslam_pose_msg* out);
 int aslam_get_map_markers(aslam_ctx* ctx, int max, int* n, aslam_marker_msg* out);
 int aslam_get_detected_markers(aslam_ctx* ctx, int max, int* n, aslam_marker_msg* out);
 
+/* MapLoader::loadMap (map_loader.cpp:7-118): the ground-truth map file "id length x y [z [roll [pitch [yaw]]]]" behind the
+ * latched real_map topic, parsed with the loader's own rules ('#' comments, malformed line => empty map, short line skipped,
+ * the crossed roll / yaw fallbacks) into marker messages (frame "world", rgba (1,1,1,.5)).  Host only; ctx may be NULL. */
+int aslam_load_map_txt(aslam_ctx* ctx, const char* path, int max, int* n, aslam_marker_msg* out);
+
 /* filter state (mu, sigma, landmark ids, armed flag) to / from a file; no counterpart in the reference (warm starts) */
 int aslam_save_state(aslam_ctx* ctx, const char* path);
 int aslam_load_state(aslam_ctx* ctx, const char* path);

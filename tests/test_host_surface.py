@@ -90,3 +90,31 @@ def test_state_round_trip_through_a_file(ran, tmp_path):
         small.load_state(f)                                        # does not fit
     with pytest.raises(capi.AslamError):
         b.load_state(tmp_path / "missing.bin")
+
+
+def test_map_file_loader_follows_the_reference_rules(tmp_path):
+    """MapLoader::loadMap (map_loader.cpp:7-81): comments, blank lines, short lines, optional fields and their crossed fallbacks"""
+    ctx = capi.Context(max_rows=64, max_cols=64, max_batch=1, persistent_waves=4, max_landmarks=4)
+    f = tmp_path / "map.txt"
+    f.write_text("# id length x y z roll pitch yaw\n"
+                 "0 0.27 5.1 0 0.3 0 -1.5708 0\n"
+                 "\n"
+                 "3\t0.27\t4 0.6 0.3 1.5708 -0 0.25\n"
+                 "7 0.2 1 2\n"                      # only the mandatory fields
+                 "9 0.2 1\n"                        # too short: skipped
+                 "11 0.3 -1 -2 0.5 0.7\n")          # roll given, pitch and yaw missing
+    mk = ctx.load_map_txt(f)
+    assert [m["id"] for m in mk] == [0, 3, 7, 11]
+    assert mk[0]["scale"] == (0.27, 0.27, 0.01) and mk[0]["color"] == (1.0, 1.0, 1.0, 0.5) and mk[0]["lifetime"] == 0.0
+    assert np.array_equal(mk[1]["position"], [4, 0.6, 0.3])
+    assert np.allclose(quat_matrix(mk[0]["orientation"]), rpy_matrix(0, -1.5708, 0), atol=1e-15)
+    assert np.allclose(quat_matrix(mk[1]["orientation"]), rpy_matrix(1.5708, 0, 0.25), atol=1e-15)
+    # line "7 ...": z -> 0; no roll -> yaw = 0 (roll stays 1.5708 from the previous line until...) no pitch -> 0; no yaw -> roll = 0
+    assert np.array_equal(mk[2]["position"], [1, 2, 0]) and np.allclose(quat_matrix(mk[2]["orientation"]), np.eye(3), atol=1e-15)
+    # line "11 ...": roll = 0.7 is read, pitch missing -> 0, yaw missing -> ROLL zeroed (the crossed fallback), yaw keeps 0
+    assert np.allclose(quat_matrix(mk[3]["orientation"]), np.eye(3), atol=1e-15)
+    g = tmp_path / "bad.txt"
+    g.write_text("1 0.27 0 0\nx 1 2 3\n2 0.27 1 1\n")
+    assert ctx.load_map_txt(g) == []                                 # malformed line: the loader clears the map and stops
+    with pytest.raises(capi.AslamError):
+        ctx.load_map_txt(tmp_path / "missing.txt")
