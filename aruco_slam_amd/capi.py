@@ -90,6 +90,8 @@ _SIGS = {
     "aslam_get_pose_msg": (C.c_int, [C.c_void_p, C.c_void_p]),
     "aslam_get_map_markers": (C.c_int, [C.c_void_p, C.c_int, _ip, C.c_void_p]),
     "aslam_get_detected_markers": (C.c_int, [C.c_void_p, C.c_int, _ip, C.c_void_p]),
+    "aslam_export_map_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "aslam_export_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "aslam_load_map_txt": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_void_p]),
     "aslam_save_state": (C.c_int, [C.c_void_p, C.c_char_p]),
     "aslam_load_state": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -221,6 +223,12 @@ class Context:
 
     def detected_markers(self):
         return self._markers(self.lib.aslam_get_detected_markers)
+
+    def export_map_async(self, device_ptr, buffer):
+        self._ck(self.lib.aslam_export_map_async(self.h, C.c_void_p(int(device_ptr)), int(buffer)))
+
+    def export_wait(self, buffer):
+        self._ck(self.lib.aslam_export_wait(self.h, int(buffer)))
 
     def load_map_txt(self, path):
         n = C.c_int(0)

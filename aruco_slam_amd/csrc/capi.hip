@@ -36,6 +36,7 @@ struct aslam_ctx {
     hipStream_t stream = nullptr;         // detection + pose (batched over frames)
     hipStream_t stream_part = nullptr;    // detection beside an EKF chain: CU-masked so that part of every XCD stays free for the chain
     hipStream_t last_detect = nullptr;    // stream of the most recent detection (ordering when it changes)
+    hipEvent_t ev_export[2] = {nullptr, nullptr};   // aslam_export_map_async: the records of buffer 0 / 1 are in place
     hipStream_t stream_copy = nullptr;    // host-fed stream: uploads from the pinned ring
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_det[2] = {nullptr, nullptr};   // per ring half: upload done / detection done with the slots
     bool ev_det_set[2] = {false, false}, ev_up_set[2] = {false, false};
@@ -516,6 +517,7 @@ void aslam_destroy(aslam_ctx* c) {
     if (c->ev_ekf) hipEventDestroy(c->ev_ekf);
     if (c->stream_copy) { hipStreamSynchronize(c->stream_copy); hipStreamDestroy(c->stream_copy); }
     for (int h = 0; h < 2; h++) { if (c->ev_up[h]) hipEventDestroy(c->ev_up[h]); if (c->ev_det[h]) hipEventDestroy(c->ev_det[h]); }
+    for (int h = 0; h < 2; h++) if (c->ev_export[h]) hipEventDestroy(c->ev_export[h]);
     if (c->h_ring) hipHostFree(c->h_ring);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->stream_part) hipStreamDestroy(c->stream_part);
@@ -1162,6 +1164,22 @@ int aslam_export_map(aslam_ctx* c, void* dst, int dst_is_device) {
     HIP_TRY(c, hipMemcpyAsync(dst, c->ekf.d_maprec, (size_t)ASLAM_MAP_RECORD_BYTES * c->ekf.max_landmarks,
                               dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream_ekf));
     HIP_TRY(c, hipStreamSynchronize(c->stream_ekf));
+    return ASLAM_OK;
+}
+
+int aslam_export_map_async(aslam_ctx* c, void* d_dst, int buffer) {
+    if (!c || !d_dst || buffer < 0 || buffer > 1) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    if (!c->ev_export[buffer]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_export[buffer], hipEventDisableTiming));
+    launch_ekf_export_map(c->stream_ekf, c->ekf);              // ordered after the EKF steps enqueued so far
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(d_dst, c->ekf.d_maprec, (size_t)ASLAM_MAP_RECORD_BYTES * c->ekf.max_landmarks, hipMemcpyDeviceToDevice, c->stream_ekf));
+    HIP_TRY(c, hipEventRecord(c->ev_export[buffer], c->stream_ekf));
+    return ASLAM_OK;
+}
+
+int aslam_export_wait(aslam_ctx* c, int buffer) {
+    if (!c || buffer < 0 || buffer > 1) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    if (c->ev_export[buffer]) HIP_TRY(c, hipEventSynchronize(c->ev_export[buffer]));
     return ASLAM_OK;
 }
 

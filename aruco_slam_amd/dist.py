@@ -49,6 +49,47 @@ class MapGather:
             self.all.copy_(self.mine)
         return self.all
 
+    # -- pipelined variant (GPU only): export step k behind its EKF chain, gather step k-1 meanwhile ----------------
+    def gather_pipelined(self):
+        """Enqueue the export of the map as of the EKF steps submitted so far and all-gather the PREVIOUS call's export, so
+        the host never waits for the step it has just submitted (the stream keeps its detection / EKF overlap).  The result
+        returned lags one call behind; flush() delivers the last one."""
+        assert self.on_gpu
+        if not hasattr(self, "_bufs"):
+            self._bufs = [self.mine, self.torch.zeros_like(self.mine)]
+            self._k = 0
+            self._work = None
+        cur = self._k & 1
+        self._finish_collective()                               # the one enqueued a whole step ago: done by now
+        self.ctx.export_map_async(self._bufs[cur].data_ptr(), cur)
+        if self._k > 0:
+            self._gather_buffer(cur ^ 1)
+        self._k += 1
+        return self.all
+
+    def _gather_buffer(self, b):
+        self.ctx.export_wait(b)
+        if self.world > 1:
+            self._work = self.dist.all_gather_into_tensor(self.all, self._bufs[b], async_op=True)
+        else:
+            self.all.copy_(self._bufs[b])
+
+    def _finish_collective(self):
+        # The library writes the export buffers on its own HIP stream, which torch knows nothing about: before a buffer is
+        # reused the collective that read it must have completed on the device, not merely be ordered on torch's stream.
+        if self._work is not None:
+            self._work.wait()
+            self.torch.cuda.current_stream().synchronize()
+            self._work = None
+
+    def flush(self):
+        if getattr(self, "_k", 0) > 0:
+            self._finish_collective()
+            self._gather_buffer((self._k - 1) & 1)
+            self._finish_collective()
+            self.torch.cuda.current_stream().synchronize()
+        return self.all
+
     def records(self):
         """gathered maps as a (world, max_landmarks) structured array (host copy)"""
         buf = self.all.cpu().numpy().tobytes()

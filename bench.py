@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=400, help="frames timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-ekf", action="store_true", help="detect + pose only (BASELINE config 5 style)")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts of the work-queue kernels (0 = library default)")
+    ap.add_argument("--force-gather", action="store_true", help="run the (pipelined) map gather even with one rank (development check)")
     ap.add_argument("--reserve", type=int, default=0, help="CUs per XCD kept free of detection beside the EKF chain (0 = library default 16, <0 = off)")
     args = ap.parse_args()
 
@@ -90,7 +91,7 @@ def main():
         if rank == 0 and args.cpu_sample > 0:
             map_mu, map_sigma = ctx.get_state()
             map_ids = ctx.get_landmark_ids()
-    gather = MapGather(ctx, device=f"cuda:{local_rank}") if world > 1 else None
+    gather = MapGather(ctx, device=f"cuda:{local_rank}") if (world > 1 or args.force_gather) else None
 
     pos = [0]
 
@@ -103,11 +104,12 @@ def main():
             run_range(0, B - (lap - first))
         pos[0] = (first + B) % lap
         if gather is not None:
-            ctx.sync()
-            gather.gather()
+            gather.gather_pipelined()                  # export behind this step's EKF chain, all-gather of the previous step's map
 
     def barrier():
         ctx.sync()
+        if gather is not None:
+            gather.flush()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -220,7 +222,7 @@ def main():
                                    f"{world_scene.L}-landmark EKF (N={N}), frames resident in HBM",
                        "frames_per_step": B, "streams": world, "ekf": with_ekf,
                        "updates_in_last_frame": int((act == 1).sum()) if with_ekf else 0,
-                       "map_gather": "rccl all_gather per step" if world > 1 else "none"},
+                       "map_gather": "rccl all_gather per step, pipelined one step behind" if world > 1 else "none"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -189,6 +189,11 @@ int aslam_detect_batch(aslam_ctx* ctx, const uint8_t* frames, int nframes, int r
  * Fixed-size record per landmark: { int32 id, int32 index, f64 x, y, theta, f64 Sigma_ll[9] } = 104 bytes.
  * Writes max_landmarks records (unused ones have id = -1) to a host or device buffer. */
 int aslam_export_map(aslam_ctx* ctx, void* dst, int dst_is_device);
+/* the same without stalling the pipeline: the export is enqueued behind the EKF steps submitted so far and lands in the
+ * device buffer d_dst; aslam_export_wait(buffer) blocks until that particular export (buffer 0 or 1) is complete, so a caller
+ * can gather step k-1's map while step k is already running on the GPU */
+int aslam_export_map_async(aslam_ctx* ctx, void* d_dst, int buffer);
+int aslam_export_wait(aslam_ctx* ctx, int buffer);
 #define ASLAM_MAP_RECORD_BYTES 104
 
 /* ---- instrumentation ---------------------------------------------------------------------------------

@@ -248,3 +248,32 @@ def test_alternating_detection_only_and_full_calls_share_slots_safely():
     for i in (0, 3, 9, 23):
         da, db = a.get_slot_detections(i), b.get_slot_detections(i)
         assert all(np.array_equal(x, y) for x, y in zip(da, db))
+
+
+def test_pipelined_map_gather_delivers_the_same_records():
+    """MapGather.gather_pipelined (export enqueued behind the EKF chain, collective one call behind) == the blocking export"""
+    import torch
+    from aruco_slam_amd.dist import MapGather, MAP_DTYPE
+    cfg = synth.CONFIGS["cfg1"]
+    w = synth.PanelWorld(cfg)
+    n = 8
+    ctx = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=n, max_landmarks=16)
+    ctx.set_camera(w.K, np.zeros(5))
+    frs = [w.frame(i) for i in range(n)]
+    for i, fr in enumerate(frs):
+        ctx.synth_render(i, cfg.rows, cfg.cols, w.K, fr.ids, fr.poses, noise_amp=1, seed=i, download=False)
+    ctx.stage_encoders([f.wl for f in frs], [f.wr for f in frs], [f.dt for f in frs])
+    g = MapGather(ctx, device="cuda:0")
+    ctx.run_staged(0, 4, with_ekf=True)
+    g.gather_pipelined()                                       # nothing delivered yet
+    ctx.sync()
+    after_first = np.frombuffer(ctx.export_map().tobytes(), dtype=MAP_DTYPE).copy()
+    ctx.run_staged(4, 4, with_ekf=True)
+    g.gather_pipelined()                                       # delivers the map as of the first call
+    torch.cuda.synchronize()
+    assert np.array_equal(g.records()[0], after_first)
+    g.flush()                                                  # delivers the map as of the second call
+    ctx.sync()
+    final = np.frombuffer(ctx.export_map().tobytes(), dtype=MAP_DTYPE)
+    assert np.array_equal(g.records()[0], final)
+    assert (final["id"] >= 0).sum() == len(ctx.get_landmark_ids())
