@@ -176,9 +176,14 @@ def main():
             traffic = int((pmc.get("FETCH_SIZE_KB_per_launch", 0) + pmc.get("WRITE_SIZE_KB_per_launch", 0)) * 1024 * scale)
     except Exception:
         traffic = None
+    path_alg = cfg.rows * cfg.cols + ((16 * N * N + 16 * N) if with_ekf else 0) + 84 * world_scene.M
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6), "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2),
                 "alg_bytes_per_launch": int(alg_bytes),
+                # SURVEY §8(d) whole-path figure: ALG_BYTES per frame x frames/s against the same peak
+                "path_alg_bytes_per_frame": int(path_alg),
+                "path_achieved": round(path_alg * (world * args.steps * B / elapsed) / world / 1e9, 3),
+                "path_frac": round(path_alg * (args.steps * B / elapsed) / 8.0e12, 6),
                 "kernel_ms_per_step": {k: round(v[1] / max(args.steps, 1), 4) for k, v in prof2.items()}}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm), 1 thread, on a bounded sample of the same workload:
