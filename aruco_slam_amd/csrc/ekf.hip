@@ -1280,13 +1280,16 @@ __global__ __launch_bounds__(M64T) void k_ekf_mid64(EkfState E) {
 // Operand layout (cdna_hip_programming.md §3): A[i][k] in lane k*16+i, B[k][j] in lane k*16+j, D rows (lane>>4)+4*reg, col lane&15.
 
 constexpr int MUK = 8;                   // depth rows of T / W^T staged per chunk
-constexpr int MUC = 128, MUR = 64;       // workgroup tile: MUC columns x MUR rows of Sigma, one wavefront per 64 columns
+constexpr int MUR = 64;                  // rows of Sigma per workgroup
 
-// Workgroup = 2 wavefronts, tile = 64 rows x 128 columns: at N = 3003 that is 47 x 24 = 1128 workgroups of 24 KB LDS, i.e. all
-// but a tenth of them resident at once on 256 CUs x 4 (the 128 x 128 tiles of a 4-wave workgroup left half of the second
-// round of workgroups empty).  The Sigma tile is loaded straight into the accumulators before the depth loop (its latency
-// hides behind the first chunks) and the product is subtracted by negating one operand: the epilogue is a pure store.
+// Workgroup = 2 wavefronts, tile = 64 rows x (2 x 16 WCT) columns, WCT = 4 or 5 MFMA column tiles per wavefront.  The host picks
+// the width that lets ALL workgroups be resident at once (4 per CU: 2 wavefronts per SIMD at this register footprint): at
+// N = 3003, 128-wide tiles make 1128 workgroups = a second, nearly empty round, 160-wide ones 893 <= 1024.  The Sigma tile is
+// loaded straight into the accumulators before the depth loop (its latency hides behind the first chunks) and the product
+// is subtracted by negating one operand: the epilogue is a pure store.
+template <int WCT>
 __global__ __launch_bounds__(128) void k_ekf_update_mfma(EkfState E) {
+    constexpr int MUC = 2 * 16 * WCT;                              // columns per workgroup
     __shared__ double sT[2][MUK][MUC];
     __shared__ double sW[2][MUK][MUR];
     const int m = *E.d_m;
@@ -1298,21 +1301,27 @@ __global__ __launch_bounds__(128) void k_ekf_update_mfma(EkfState E) {
     if (cb0 >= N || rb0 >= N) return;                              // uniform per workgroup
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int wc = wave * 64;                                      // this wavefront's 64 columns (all 64 rows)
+    const int wc = wave * 16 * WCT;                                // this wavefront's columns (all 64 rows)
     const int li = lane & 15, lk = lane >> 4;
 
-    // chunk loader: MUK x (128 + 64) doubles = 8 of T and 4 of W^T per thread, issued in bulk
+    // chunk loader: MUK x (MUC + 64) doubles, issued in bulk: T rows by (tid, tid + 128), W^T rows split by wavefront
+    constexpr int NTL = (MUC + 127) / 128;                         // T columns per thread (1 or 2)
     const int wx = tid & 63, wp = tid >> 6;
-    double pt[MUK], pw[MUK / 2];
+    double pt[MUK][NTL], pw[MUK / 2];
     const int nchunks = (n3 + MUK - 1) / MUK;
 #pragma unroll
-    for (int k = 0; k < MUK; k++) pt[k] = (k < n3 && cb0 + tid < N) ? E.d_T[(size_t)k * ld + cb0 + tid] : 0.0;
+    for (int k = 0; k < MUK; k++)
+#pragma unroll
+        for (int q = 0; q < NTL; q++) {
+            const int x = tid + 128 * q;
+            pt[k][q] = (x < MUC && k < n3 && cb0 + x < N) ? E.d_T[(size_t)k * ld + cb0 + x] : 0.0;
+        }
 #pragma unroll
     for (int k = 0; k < MUK / 2; k++) { const int p = wp + 2 * k; pw[k] = (p < n3 && rb0 + wx < N) ? E.d_Wt[(size_t)p * ld + rb0 + wx] : 0.0; }
 
-    v4d acc[4][4];                                                 // D'[c][r]: register reg of acc[ci][ri] = Sigma(r = 16 ri + li, c = 16 ci + lk + 4 reg)
+    v4d acc[WCT][4];                                               // D'[c][r]: register reg of acc[ci][ri] = Sigma(r = 16 ri + li, c = 16 ci + lk + 4 reg)
 #pragma unroll
-    for (int ci = 0; ci < 4; ci++)
+    for (int ci = 0; ci < WCT; ci++)
 #pragma unroll
         for (int ri = 0; ri < 4; ri++)
 #pragma unroll
@@ -1324,31 +1333,40 @@ __global__ __launch_bounds__(128) void k_ekf_update_mfma(EkfState E) {
     for (int ch = 0; ch < nchunks; ch++) {
         const int buf = ch & 1;
 #pragma unroll
-        for (int k = 0; k < MUK; k++) sT[buf][k][tid] = pt[k];
+        for (int k = 0; k < MUK; k++)
+#pragma unroll
+            for (int q = 0; q < NTL; q++) { const int x = tid + 128 * q; if (x < MUC) sT[buf][k][x] = pt[k][q]; }
 #pragma unroll
         for (int k = 0; k < MUK / 2; k++) sW[buf][wp + 2 * k][wx] = pw[k];
         __syncthreads();
         if (ch + 1 < nchunks) {                                    // prefetch the next chunk while this one is multiplied
             const int pb = (ch + 1) * MUK;
 #pragma unroll
-            for (int k = 0; k < MUK; k++) pt[k] = (pb + k < n3 && cb0 + tid < N) ? E.d_T[(size_t)(pb + k) * ld + cb0 + tid] : 0.0;
+            for (int k = 0; k < MUK; k++)
+#pragma unroll
+                for (int q = 0; q < NTL; q++) {
+                    const int x = tid + 128 * q;
+                    pt[k][q] = (x < MUC && pb + k < n3 && cb0 + x < N) ? E.d_T[(size_t)(pb + k) * ld + cb0 + x] : 0.0;
+                }
 #pragma unroll
             for (int k = 0; k < MUK / 2; k++) { const int p = pb + wp + 2 * k; pw[k] = (p < n3 && rb0 + wx < N) ? E.d_Wt[(size_t)p * ld + rb0 + wx] : 0.0; }
         }
 #pragma unroll
         for (int kk = 0; kk < MUK / 4; kk++) {
-            double a[4], b[4];
+            double a[WCT], b[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { a[q] = -sT[buf][kk * 4 + lk][wc + 16 * q + li]; b[q] = sW[buf][kk * 4 + lk][16 * q + li]; }
+            for (int q = 0; q < WCT; q++) a[q] = -sT[buf][kk * 4 + lk][wc + 16 * q + li];
 #pragma unroll
-            for (int ci = 0; ci < 4; ci++)
+            for (int q = 0; q < 4; q++) b[q] = sW[buf][kk * 4 + lk][16 * q + li];
+#pragma unroll
+            for (int ci = 0; ci < WCT; ci++)
 #pragma unroll
                 for (int ri = 0; ri < 4; ri++) acc[ci][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ci], b[ri], acc[ci][ri], 0, 0, 0);
         }
         // the other buffer is rewritten next iteration: every wave has finished reading it one iteration ago (barrier above)
     }
 #pragma unroll
-    for (int ci = 0; ci < 4; ci++)
+    for (int ci = 0; ci < WCT; ci++)
 #pragma unroll
         for (int ri = 0; ri < 4; ri++)
 #pragma unroll
@@ -1465,7 +1483,12 @@ void launch_ekf_mid64(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_mid64, dim3(1 + ncg * 16), dim3(M64T), 0, st, E);
 }
 void launch_ekf_update_mfma(hipStream_t st, const EkfState& E) {
-    hipLaunchKernelGGL(k_ekf_update_mfma, dim3((E.ld + MUR - 1) / MUR, (E.ld + MUC - 1) / MUC), dim3(128), 0, st, E);
+    // the narrowest tile whose workgroups all fit on the device at once (256 CUs x 4); N_max stands in for the current N
+    const int rt = (E.ld + MUR - 1) / MUR;
+    if (rt * ((E.ld + 127) / 128) <= 1024 || rt * ((E.ld + 159) / 160) > 1024)
+        hipLaunchKernelGGL(k_ekf_update_mfma<4>, dim3(rt, (E.ld + 127) / 128), dim3(128), 0, st, E);
+    else
+        hipLaunchKernelGGL(k_ekf_update_mfma<5>, dim3(rt, (E.ld + 159) / 160), dim3(128), 0, st, E);
 }
 void launch_ekf_export_map(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_export_map, dim3((E.max_landmarks + 255) / 256), dim3(256), 0, st, E);
