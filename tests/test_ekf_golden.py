@@ -16,7 +16,7 @@ GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)
 
 
 def replay(path, batch, max_updates=24):
-    g = np.load(path)
+    g = np.load(path) if isinstance(path, str) else path
     nfr = int(g["n_frames"])
     r2c = g["r2c"]
     ctx = capi.Context(max_rows=64, max_cols=64, max_batch=nfr, persistent_waves=4, max_landmarks=32, max_updates_per_frame=max_updates,
@@ -91,3 +91,35 @@ def test_device_ekf_replays_golden_on_gpu(path):
     replay(path, batch=4)
     replay(path, batch=3, max_updates=64)
     replay(path, batch=2, max_updates=100)
+
+
+def _fresh_case(seed):
+    """cases drawn at test time by the golden generator (oracle/make_golden.py:make_case) with other seeds and shapes: duplicate
+    ids, repeated frames, gated markers, distortion; every frame against the numpy literal transcription"""
+    from oracle.make_golden import make_case
+    rng = np.random.RandomState(seed)
+    c = dict(seed=seed, n_landmarks=int(rng.randint(4, 16)), n_frames=int(rng.randint(6, 14)), per_frame=0, r2c=(float(rng.uniform(-0.2, 0.2)), float(rng.uniform(-0.2, 0.2))),
+             D=[0, 0, 0, 0, 0] if seed % 2 else [0.05, -0.04, 0.002, -0.003, 0.01], dup_frame=int(rng.randint(0, 5)) if seed % 3 else None)
+    c["per_frame"] = int(rng.randint(2, c["n_landmarks"] + 1))
+    K, frames, exp = make_case(**c)
+    g = dict(K=K, D=np.asarray(c["D"], float), r2c=np.asarray(c["r2c"], float), n_frames=len(frames))
+    for f, (fr, ex) in enumerate(zip(frames, exp)):
+        for k in ("wl", "wr", "t", "ids", "corners", "rvecs", "tvecs"):
+            g[f"in{f}_{k}"] = fr[k]
+        for k in ("mu", "sigma", "log"):
+            g[f"out{f}_{k}"] = ex[k]
+    return g
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_device_ekf_on_fresh_random_cases(seed):
+    assert replay(_fresh_case(seed), batch=1 + seed % 3).sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(21, 33))
+def test_device_ekf_on_fresh_random_cases_gpu(seed):
+    g = _fresh_case(seed)
+    assert replay(g, batch=1 + seed % 3).sum() > 0
+    replay(g, batch=2, max_updates=48)
+    replay(g, batch=1, max_updates=100)
