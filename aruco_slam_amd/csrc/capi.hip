@@ -244,7 +244,9 @@ int check_slot_range(aslam_ctx* c, int first, int count) {
 int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipEvent_t wait_before = nullptr) {
     if (c->rows == 0) return fail(c, ASLAM_E_STATE, "no frames staged");
     if (!c->have_cam) return fail(c, ASLAM_E_STATE, "camera parameters not set (aslam_set_camera)");
-    hipStream_t st = (beside_ekf && c->stream_part) ? c->stream_part : c->stream;
+    // the CU-masked stream only pays off while an EKF chain is actually in flight beside this detection; the first batch after
+    // a synchronisation gets the whole GPU
+    hipStream_t st = (beside_ekf && c->stream_part && c->ekf_count > 0) ? c->stream_part : c->stream;
     if (c->last_detect && c->last_detect != st) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_detect, 0));   // slots / work lists are shared
     c->last_detect = st;
     if (wait_before) HIP_TRY(c, hipStreamWaitEvent(st, wait_before, 0));          // frames still in flight on the copy stream
