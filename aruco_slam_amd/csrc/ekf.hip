@@ -77,6 +77,7 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
 #pragma unroll
             for (int j = 0; j < 3; j++) S[i * 3 + j] = E.d_sigma[(size_t)j * ld + i];
     }
+    double pc = 0.0, ps = 0.0;                                    // thread 0: cos / sin of the mid-step heading, kept for Qk
     if (tid == 0) {
         double delta_enl = dt * wl, delta_enr = dt * wr;
         double delta_sl = sp.kl * delta_enl, delta_sr = sp.kr * delta_enr;
@@ -87,26 +88,31 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
         double tmp_th = m2 + 0.5 * delta_theta;
         double c, s;
         sincos(tmp_th, &s, &c);
+        pc = c; ps = s;
         double th = m2 + delta_theta;
         wrap1(th);
         sMu[0] = m0 + delta_s * c; sMu[1] = m1 + delta_s * s; sMu[2] = th;
-        E.d_mu[0] = sMu[0]; E.d_mu[1] = sMu[1]; E.d_mu[2] = sMu[2];
         sH[0] = 1.0; sH[1] = 0.0; sH[2] = -delta_s * s;
         sH[3] = 0.0; sH[4] = 1.0; sH[5] = delta_s * c;
         sH[6] = 0.0; sH[7] = 0.0; sH[8] = 1.0;
+    }
+    __syncthreads();                                              // sH / sMu: all the other threads need
+    if (tid == 0) {
+        // off the other threads' path: the new pose, the process noise and the pose block H S H^T + Q (only thread 0 ever
+        // touches these entries; the callers' later barriers order them before anything reads Sigma again)
+        E.d_mu[0] = sMu[0]; E.d_mu[1] = sMu[1]; E.d_mu[2] = sMu[2];
+        const double c = pc, s = ps;
         const double f = 0.5 * sp.kl * dt;                       // kl for BOTH wheels (quirk Q7)
         double wkh[6] = {f * c, f * c, f * s, f * s, f * (1 / sp.b), f * (-1 / sp.b)};
         double su0 = sp.Q_k * fabs(wl), su1 = sp.Q_k * fabs(wr);
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++) sQ[i * 3 + j] = wkh[i * 2] * su0 * wkh[j * 2] + wkh[i * 2 + 1] * su1 * wkh[j * 2 + 1];
-        // pose block: H S H^T + Q (only thread 0 ever touches these nine entries)
         double T[9];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[i * 3 + j] = sH[i * 3] * S[j] + sH[i * 3 + 1] * S[3 + j] + sH[i * 3 + 2] * S[6 + j];
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++)
                 E.d_sigma[(size_t)j * ld + i] = (T[i * 3] * sH[j * 3] + T[i * 3 + 1] * sH[j * 3 + 1] + T[i * 3 + 2] * sH[j * 3 + 2]) + sQ[i * 3 + j];
     }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < kPredCols; k++) {
         const int t = 3 + tid + k * nt;
@@ -131,7 +137,7 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
         E.d_sigma[(size_t)ld + t] = xa * sH[3] + xb * sH[4] + xc * sH[5];
         E.d_sigma[(size_t)2 * ld + t] = xa * sH[6] + xb * sH[7] + xc * sH[8];
     }
-    __syncthreads();
+    // no barrier here: nothing below reads these entries of Sigma from another thread before the caller's next barriers
 }
 
 __global__ __launch_bounds__(256) void k_ekf_predict(EkfState E, SlamParams sp, double wl, double wr, double dt) {
