@@ -54,7 +54,7 @@ __device__ void inv3_pp(const double* A, double* out) {   // 3x3 inverse by part
 // columns 0..2 by H^T from the right; outside the 3x3 corner the two touch disjoint entries, so one pass does both
 // (thread t >= 3: entries (0..2, t) and (t, 0..2); thread 0: the corner (H S3) H^T + Qk).  sMu receives the new pose.
 __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int N,
-                              double* sH /*shared 9*/, double* sQ /*shared 9*/, double* sMu /*shared 3*/) {
+                              double* sH /*shared 9*/, double* sQ /*shared 9*/, double* sMu /*shared 5: pose, then sin / cos of the new heading*/) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int ld = E.ld;
     // every load of the pass is issued before the first dependent instruction: the three pose rows / columns of this
@@ -101,6 +101,7 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
         // off the other threads' path: the new pose, the process noise and the pose block H S H^T + Q (only thread 0 ever
         // touches these entries; the callers' later barriers order them before anything reads Sigma again)
         E.d_mu[0] = sMu[0]; E.d_mu[1] = sMu[1]; E.d_mu[2] = sMu[2];
+        sincos(sMu[2], &sMu[3], &sMu[4]);                        // for the update records (same value every thread would compute)
         const double c = pc, s = ps;
         const double f = 0.5 * sp.kl * dt;                       // kl for BOTH wheels (quirk Q7)
         double wkh[6] = {f * c, f * c, f * s, f * s, f * (1 / sp.b), f * (-1 / sp.b)};
@@ -141,7 +142,7 @@ __device__ void predict_block(const EkfState& E, const SlamParams& sp, double wl
 }
 
 __global__ __launch_bounds__(256) void k_ekf_predict(EkfState E, SlamParams sp, double wl, double wr, double dt) {
-    __shared__ double sH[9], sQ[9], sMu[3];
+    __shared__ double sH[9], sQ[9], sMu[5];
     const int N = 3 + 3 * (*E.d_L);
     predict_block(E, sp, wl, wr, dt, N, sH, sQ, sMu);
 }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void k_ekf_predict(EkfState E, SlamParams sp, 
 __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, double wl, double wr, double dt, int do_predict,
                                                   const ObsRaw* __restrict__ obs, const unsigned* __restrict__ n_markers,
                                                   Counters* ctr, int max_m) {
-    __shared__ double sH[9], sQ[9], sMu[3];
+    __shared__ double sH[9], sQ[9], sMu[5];
     __shared__ ObsRaw sObs[kMarkerMax];
     __shared__ LastObs sLast[kMarkerMax];
     __shared__ int sHeap[kMarkerMax];          // heap of observation slots
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     if (do_predict) {
         predict_block(E, sp, wl, wr, dt, 3 + 3 * L0, sH, sQ, sMu);
         mu0x = sMu[0]; mu0y = sMu[1]; mu0t = sMu[2];                             // frozen pre-frame robot pose (Q1)
+    } else if (tid == 0) {
+        sincos(mu0t, &sMu[3], &sMu[4]);
     }
     if (tid < nM) {
         sObs[tid] = myObs;
@@ -379,8 +382,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         if (up >= 0) {
             const int li = 3 + 3 * index;
             const double mx = sLm[slot][0], my = sLm[slot][1], mth = sLm[slot][2];   // mu_[li..li+2], loaded at kernel start
-            double sintheta, costheta;
-            sincos(mu0t, &sintheta, &costheta);
+            const double sintheta = sMu[3], costheta = sMu[4];                   // sin / cos of mu0t, thread 0 (barriers in between)
             double gdx = mx - mu0x, gdy = my - mu0y, gdth = mth - mu0t;
             wrap1(gdth);
             double zh0 = gdx * costheta + gdy * sintheta, zh1 = -gdx * sintheta + gdy * costheta;
