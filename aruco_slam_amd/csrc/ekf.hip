@@ -959,11 +959,14 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
         for (int a = 0; a < 3; a++) sPart[bi][bj][a] = A[a * 3] * n0 + A[a * 3 + 1] * n1 + A[a * 3 + 2] * n2;
     }
     __syncthreads();
-    if (tid < n3) {
-        const int i = tid / 3, a = tid - 3 * i;
+    if (tid < 4 * n3) {                                // four lanes per entry of g: partial sums over j = q, q + 4, ..., then two shuffles
+        const int r = tid >> 2, q = tid & 3;
+        const int i = r / 3, a = r - 3 * i;
         double s = 0;
-        for (int j = 0; j < m; j++) s += sPart[i][j][a];
-        E.d_g[tid] = s;
+        for (int j = q; j < m; j += 4) s += sPart[i][j][a];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (q == 0) E.d_g[r] = s;
     }
 }
 
