@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     __shared__ int sOrder[kMarkerMax];         // pop order
     __shared__ int sAction[kMarkerMax];        // per popped observation
     __shared__ int sUpdPos[kMarkerMax];        // position in the fused update list (-1 = none)
-    __shared__ int sNPop, sL, sM, sNNew, sDup, sWaveCnt[2];
+    __shared__ int sNPop, sL, sM, sNNew, sDup, sWaveCnt[2], sCntNew[2], sCntPop[2];
     __shared__ double sLm[kMarkerMax][3];       // landmark mean per observation slot
     __shared__ double sG[9], sMM[9], sNew[3];
     __shared__ int sDoAug;
@@ -191,14 +191,15 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         sLm[tid][0] = lmx; sLm[tid][1] = lmy; sLm[tid][2] = lmt;
     }
     if (tid < nl) sLast[tid] = myLast;
-    if (tid == 0) { sNNew = 0; sNPop = 0; sDup = 0; }
-    __syncthreads();
-    for (int i = tid; i < nM; i += nt) {
-        if (sIndex[i] == -1) atomicAdd(&sNNew, 1);
-        if (sIndex[i] != -2) atomicAdd(&sNPop, 1);
+    {
+        // how many observations are new / enter the queue: one ballot per wavefront (observations sit in threads 0..127)
+        const unsigned long long bNew = __ballot(tid < nM && myIndex == -1), bPop = __ballot(tid < nM && myIndex != -2);
+        if (tid < kMarkerMax && (tid & 63) == 0) { sCntNew[tid >> 6] = __popcll(bNew); sCntPop[tid >> 6] = __popcll(bPop); }
     }
+    if (tid == 0) sDup = 0;
     __syncthreads();
-    if (sNNew == 0) {
+    if (tid == 0) { sNNew = sCntNew[0] + sCntNew[1]; sNPop = sCntPop[0] + sCntPop[1]; }     // read after the barriers below
+    if (sCntNew[0] + sCntNew[1] == 0) {
         // Steady state (every marker already mapped): all keys of the priority queue are distinct unless one id was
         // detected twice, so the pop order is simply ascending landmark index -> rank in parallel.
         for (int i = tid; i < nM; i += nt) {
