@@ -69,7 +69,7 @@ class MapGather:
 
     def _gather_buffer(self, b):
         self.ctx.export_wait(b)
-        if self.world > 1:
+        if self.dist.is_initialized():                           # also with a single rank: the same RCCL path
             self._work = self.dist.all_gather_into_tensor(self.all, self._bufs[b], async_op=True)
         else:
             self.all.copy_(self._bufs[b])

@@ -49,7 +49,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or (args.force_gather and "RANK" in os.environ):
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = synth.CONFIGS[args.config]
@@ -235,7 +235,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
