@@ -277,3 +277,14 @@ def test_pipelined_map_gather_delivers_the_same_records():
     final = np.frombuffer(ctx.export_map().tobytes(), dtype=MAP_DTYPE)
     assert np.array_equal(g.records()[0], final)
     assert (final["id"] >= 0).sum() == len(ctx.get_landmark_ids())
+
+
+def test_pipelined_map_gather_over_rccl():
+    """the same through a real process group (one rank, backend nccl = RCCL), in a child process"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nccl_gather_worker.py")],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "nccl gather ok" in out.stdout, out.stdout + out.stderr
