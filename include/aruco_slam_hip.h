@@ -7,8 +7,8 @@
  * class with the reference's method names.  Every entry point cites the reference interface it replaces.
  *
  * Conventions: every function returns 0 on success and a negative ASLAM_E_* code on failure (never
- * throws); aslam_last_error() gives the text.  A context is bound to one HIP device and one HIP stream and
- * is NOT thread-safe (the reference relies on the single-threaded ROS spinner, aruco_slam_node.cpp:79).
+ * throws); aslam_last_error() gives the text.  A context is bound to one HIP device (it owns a few HIP streams there:
+ * detection, EKF chain, uploads) and is NOT thread-safe (the reference relies on the single-threaded ROS spinner, aruco_slam_node.cpp:79).
  * Pointers are plain host pointers unless the parameter name starts with d_.  There is no CPU fallback: on a
  * machine without a usable gfx950 device aslam_create fails with ASLAM_E_NO_DEVICE.
  */
