@@ -212,7 +212,16 @@ int configure_frames(aslam_ctx* c, int rows, int cols, int channels) {
     g.pitch = (cols + 63) / 64 * 64;
     // cv::aruco::DetectorParameters: OpenCV 3.2.0 defaults (the reference passes none, aruco_slam.cpp:313) unless replaced
     const aslam_detector_params& dp = c->dp;
-    g.win_r[0] = 1; g.win_r[1] = 6; g.win_r[2] = 11;                     // windows 3, 13, 23 (compiled into k_threshold)
+    {
+        // aruco.cpp::_detectInitialCandidates: nScales = (max - min) / step + 1 windows min + i step, even sizes bumped to odd
+        const int ns = (dp.adaptiveThreshWinSizeMax - dp.adaptiveThreshWinSizeMin) / dp.adaptiveThreshWinSizeStep + 1;
+        g.n_scales = ns;
+        for (int i = 0; i < kScales; i++) {
+            int win = dp.adaptiveThreshWinSizeMin + i * dp.adaptiveThreshWinSizeStep;
+            if (win % 2 == 0) win++;
+            g.win_r[i] = i < ns ? win / 2 : 0;
+        }
+    }
     g.thresh_c = (int)std::floor(dp.adaptiveThreshConstant);             // THRESH_BINARY_INV: src - mean <= -floor(C)
     g.min_perim = (int)(unsigned)(dp.minMarkerPerimeterRate * std::max(cols, rows));
     g.max_perim = (int)(unsigned)(dp.maxMarkerPerimeterRate * std::max(cols, rows));
@@ -714,8 +723,16 @@ void aslam_default_detector_params(aslam_detector_params* p) {
 
 int aslam_set_detector_params(aslam_ctx* c, const aslam_detector_params* p) {
     if (!c || !p) return ASLAM_E_INVALID;
-    if (p->adaptiveThreshWinSizeMin != 3 || p->adaptiveThreshWinSizeMax != 23 || p->adaptiveThreshWinSizeStep != 10)
-        return fail(c, ASLAM_E_INVALID, "adaptiveThreshWinSize{Min,Max,Step} are compiled in as 3/23/10");
+    {
+        // the LDS tile carries a 12-pixel halo and three mask planes: up to 3 windows of at most 23 pixels
+        const int step = p->adaptiveThreshWinSizeStep;
+        const int ns = step > 0 && p->adaptiveThreshWinSizeMax >= p->adaptiveThreshWinSizeMin
+                           ? (p->adaptiveThreshWinSizeMax - p->adaptiveThreshWinSizeMin) / step + 1 : 0;
+        int last = p->adaptiveThreshWinSizeMin + (ns - 1) * step;
+        if (last % 2 == 0) last++;
+        if (ns < 1 || ns > kScales || p->adaptiveThreshWinSizeMin < 3 || last > 23)
+            return fail(c, ASLAM_E_INVALID, "adaptive threshold windows: 1..3 sizes (min + i step) between 3 and 23 pixels");
+    }
     if (p->perspectiveRemovePixelPerCell != kCellPx) return fail(c, ASLAM_E_INVALID, "perspectiveRemovePixelPerCell is compiled in as 8");
     if (p->markerBorderBits != 1) return fail(c, ASLAM_E_INVALID, "markerBorderBits is compiled in as 1");
     if (p->doCornerRefinement && (p->cornerRefinementWinSize < 1 || p->cornerRefinementWinSize > 7 || p->cornerRefinementMaxIterations < 1 ||

@@ -22,7 +22,8 @@ enum : unsigned {
 // Everything the detector kernels need to know about one batch (host-filled, passed by value).
 struct DetectCfg {
     int rows, cols, pitch;            // pitch of the neighbour-mask planes (multiple of 64)
-    int win_r[kScales];               // box radius per scale: 1, 6, 11
+    int win_r[kScales];               // box radius per scale: 1, 6, 11 by default
+    int n_scales;                     // threshold windows in use (1..kScales)
     int thresh_c;                     // floor(adaptiveThreshConstant) = 7
     int min_perim, max_perim;         // contour point-count bounds
     double approx_rate;               // polygonalApproxAccuracyRate (0.05)

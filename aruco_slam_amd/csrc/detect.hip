@@ -38,6 +38,14 @@ template <int R> __device__ __forceinline__ unsigned box_mean(const unsigned (*I
     return (2u * sum + k2) / (2u * k2);       // round-to-nearest; k2 is odd so a tie cannot occur (division by a constant)
 }
 
+// runtime window radius (DetectorParameters other than the default 3 / 13 / 23): the same exact rounding, division by a variable
+__device__ __forceinline__ unsigned box_mean_r(const unsigned (*I)[LW + 1], int ly, int lx, int R) {
+    const unsigned k2 = (unsigned)((2 * R + 1) * (2 * R + 1));
+    const unsigned sum = I[ly + R + 1][lx + R + 1] - I[ly - R][lx + R + 1] - I[ly + R + 1][lx - R] + I[ly - R][lx - R];
+    return (2u * sum + k2) / (2u * k2);
+}
+
+template <bool kDefaultWindows>
 __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ in, int channels, size_t in_frame_stride,
                                                    size_t in_row_step, uint8_t* __restrict__ gray_out,
                                                    uint8_t* __restrict__ nbr, DetectCfg cfg,
@@ -146,9 +154,15 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         if (gx >= 0 && gx < cols && gy >= 0 && gy < rows) {
             int lx = bx - 1 + HALO, ly = by - 1 + HALO;
             int v = g[ly][lx];
-            if (v - (int)box_mean<1>(I, ly, lx) <= -cfg.thresh_c) bits |= 1u;
-            if (v - (int)box_mean<6>(I, ly, lx) <= -cfg.thresh_c) bits |= 2u;
-            if (v - (int)box_mean<11>(I, ly, lx) <= -cfg.thresh_c) bits |= 4u;
+            if (kDefaultWindows) {
+                if (v - (int)box_mean<1>(I, ly, lx) <= -cfg.thresh_c) bits |= 1u;
+                if (v - (int)box_mean<6>(I, ly, lx) <= -cfg.thresh_c) bits |= 2u;
+                if (v - (int)box_mean<11>(I, ly, lx) <= -cfg.thresh_c) bits |= 4u;
+            } else {
+#pragma unroll
+                for (int s = 0; s < kScales; s++)
+                    if (s < cfg.n_scales && v - (int)box_mean_r(I, ly, lx, cfg.win_r[s]) <= -cfg.thresh_c) bits |= 1u << s;
+            }
         }
         bin[by][bx] = (uint8_t)bits;
     }
@@ -1022,8 +1036,13 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
 void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t frame_stride, size_t row_step, int nframes,
                       uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, Counters* ctr) {
     const unsigned total = (unsigned)((cfg.cols + TW - 1) / TW) * (unsigned)((cfg.rows + TH - 1) / TH) * (unsigned)nframes;
-    hipLaunchKernelGGL(k_threshold, dim3((total + 7u) / 8u * 8u), dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg, starts,
-                       n_starts, ctr, nframes);
+    const bool def = cfg.n_scales == 3 && cfg.win_r[0] == 1 && cfg.win_r[1] == 6 && cfg.win_r[2] == 11;
+    if (def)
+        hipLaunchKernelGGL(k_threshold<true>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg,
+                           starts, n_starts, ctr, nframes);
+    else
+        hipLaunchKernelGGL(k_threshold<false>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg,
+                           starts, n_starts, ctr, nframes);
 }
 void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre) {
     hipLaunchKernelGGL(k_prefix, dim3(1), dim3(256), 0, st, nframes, counts, cap, per_ticket, pre);

@@ -21,11 +21,11 @@ def nbr_from_binary(fg):
     return m
 
 
-def check_stages(ctx, slot, img, expect_ids=None, perim_rates=(0.03, 4.0), thresh_c=7.0):
+def check_stages(ctx, slot, img, expect_ids=None, perim_rates=(0.03, 4.0), thresh_c=7.0, windows=(3, 13, 23)):
     """threshold -> contours -> candidates -> detections of one staged frame against the oracle."""
     rows, cols = img.shape
     lo, hi = int(perim_rates[0] * max(rows, cols)), int(perim_rates[1] * max(rows, cols))
-    for s, k in enumerate((3, 13, 23)):
+    for s, k in enumerate(windows):
         th = orc.threshold(img, k, thresh_c)
         assert np.array_equal(ctx.debug_nbr(slot, s, rows, cols), nbr_from_binary(th > 0)), f"neighbour masks differ at scale {s}"
         sizes, keys, hole, pts = orc.find_contours(th)

@@ -122,3 +122,21 @@ def test_corner_refinement_full_frame(refine_params):
     ctx, ids, poses, K = _scene(rows, cols, 900.0, 20, 3, (1.9, 2.6))
     got, corners, rv, tv = _refined(ctx, rows, cols, K, ids, poses, refine_params, 7)
     pc.check_poses(got, corners, rv, tv, K, np.zeros(5))
+
+
+@pytest.mark.parametrize("wins,kw", [((5, 13, 21), dict(adaptiveThreshWinSizeMin=5, adaptiveThreshWinSizeMax=21, adaptiveThreshWinSizeStep=8)),
+                                     ((7,), dict(adaptiveThreshWinSizeMin=6, adaptiveThreshWinSizeMax=6, adaptiveThreshWinSizeStep=4)),
+                                     ((9, 19), dict(adaptiveThreshWinSizeMin=9, adaptiveThreshWinSizeMax=22, adaptiveThreshWinSizeStep=10))])
+def test_other_threshold_windows_match_oracle(wins, kw):
+    """window sizes min + i step (even sizes bumped to odd, aruco.cpp::_detectInitialCandidates): 1..3 of them, 3..23 pixels"""
+    rows, cols = 240, 320
+    ctx, ids, poses, K = _scene(rows, cols, 300.0, 3, 1, (0.9, 1.4))
+    orc.set_detector_params(**kw)
+    try:
+        ctx.set_detector_params(**kw)
+        img = ctx.synth_render(0, rows, cols, K, ids, poses, noise_amp=3, seed=5)
+        ctx.run_staged(0, 1, with_ekf=False)
+        ctx.sync()
+        pc.check_stages(ctx, 0, img, expect_ids=ids, windows=wins)
+    finally:
+        orc.set_detector_params()
