@@ -231,7 +231,8 @@ int configure_frames(aslam_ctx* c, int rows, int cols, int channels) {
     g.min_border_dist = dp.minDistanceToBorder;
     g.marker_size = c->dict_ms;
     g.border_bits = dp.markerBorderBits;
-    g.cell_margin = (int)(dp.perspectiveRemoveIgnoredMarginPerCell * kCellPx);
+    g.cell_px = dp.perspectiveRemovePixelPerCell;
+    g.cell_margin = (int)(dp.perspectiveRemoveIgnoredMarginPerCell * g.cell_px);
     g.max_border_err = (int)(c->dict_ms * c->dict_ms * dp.maxErroneousBitsInBorderRate);
     g.max_corr = (int)((double)c->dict_maxcorr * dp.errorCorrectionRate);
     g.n_dict = c->dict_n;
@@ -733,7 +734,9 @@ int aslam_set_detector_params(aslam_ctx* c, const aslam_detector_params* p) {
         if (ns < 1 || ns > kScales || p->adaptiveThreshWinSizeMin < 3 || last > 23)
             return fail(c, ASLAM_E_INVALID, "adaptive threshold windows: 1..3 sizes (min + i step) between 3 and 23 pixels");
     }
-    if (p->perspectiveRemovePixelPerCell != kCellPx) return fail(c, ASLAM_E_INVALID, "perspectiveRemovePixelPerCell is compiled in as 8");
+    if (p->perspectiveRemovePixelPerCell < 2 || p->perspectiveRemovePixelPerCell > kCellPx ||
+        p->perspectiveRemovePixelPerCell - 2 * (int)(p->perspectiveRemoveIgnoredMarginPerCell * p->perspectiveRemovePixelPerCell) < 1)
+        return fail(c, ASLAM_E_INVALID, "perspectiveRemovePixelPerCell: 2..8, with at least one pixel left inside the margin");
     if (p->markerBorderBits != 1) return fail(c, ASLAM_E_INVALID, "markerBorderBits is compiled in as 1");
     if (p->doCornerRefinement && (p->cornerRefinementWinSize < 1 || p->cornerRefinementWinSize > 7 || p->cornerRefinementMaxIterations < 1 ||
                                   !(p->cornerRefinementMinAccuracy > 0)))

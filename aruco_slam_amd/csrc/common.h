@@ -12,7 +12,7 @@ constexpr int kScales = 3;        // adaptive-threshold windows 3, 13, 23 (Detec
 constexpr int kCandMax = 2048;    // quad candidates kept per frame
 constexpr int kMarkerMax = 128;   // identified markers / observations per frame
 constexpr int kDictMaxCells = 9;  // markerSize + 2 border cells <= 9 (7x7 dictionaries)
-constexpr int kCellPx = 8;        // perspectiveRemovePixelPerCell (3.2.0 default)
+constexpr int kCellPx = 8;        // largest perspectiveRemovePixelPerCell (= the 3.2.0 default; 4 from 3.3)
 
 // overflow / error bits reported by the device in Counters::overflow
 enum : unsigned {
@@ -32,6 +32,7 @@ struct DetectCfg {
     int min_border_dist;              // minDistanceToBorder (3)
     int marker_size;                  // dictionary markerSize (5)
     int border_bits;                  // markerBorderBits (1)
+    int cell_px;                      // perspectiveRemovePixelPerCell (<= kCellPx)
     int cell_margin;                  // int(0.13 * cellSize) = 1
     int max_border_err;               // int(ms*ms*0.35)
     int max_corr;                     // int(maxCorrectionBits * errorCorrectionRate)

@@ -842,7 +842,8 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
     const int rows = cfg.rows, cols = cfg.cols;
     const int ms = cfg.marker_size, bb = cfg.border_bits;
     const int nc = ms + 2 * bb;                 // cells per side
-    const int S = nc * kCellPx;                 // warped image side
+    const int cell = cfg.cell_px;
+    const int S = nc * cell;                    // warped image side
     const unsigned n_work = ctr->n_ident;
 
     for (;;) {
@@ -914,7 +915,7 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
         __syncthreads();
 
         // warpPerspective(INTER_NEAREST), histogram, inner-region moments
-        const int lo = kCellPx / 2, hi = S - kCellPx / 2;
+        const int lo = cell / 2, hi = S - cell / 2;
         long long sum = 0, sq = 0;
         for (int p = lane; p < S * S; p += 64) {
             int y = p / S, x = p - y * S;
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
         unsigned long long bitsLo = 0, bitsHi = 0;       // cell index c -> bit c (lo) / c - 64 (hi)
         {
             const int dec = sDecision[0], T = sDecision[1];
-            const int wcell = kCellPx - 2 * cfg.cell_margin;
+            const int wcell = cell - 2 * cfg.cell_margin;
             for (int half = 0; half < 2; half++) {
                 int c = lane + 64 * half;
                 int bit = 0;
@@ -975,7 +976,7 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
                     if (dec == 2) bit = 1;
                     else if (dec == 0) {
                         int cy = c / nc, cx = c - cy * nc;
-                        int Xs = cx * kCellPx + cfg.cell_margin, Ys = cy * kCellPx + cfg.cell_margin;
+                        int Xs = cx * cell + cfg.cell_margin, Ys = cy * cell + cfg.cell_margin;
                         int nz = 0;
                         for (int yy = 0; yy < wcell; yy++)
                             for (int xx = 0; xx < wcell; xx++) nz += img[(Ys + yy) * S + Xs + xx] > T;

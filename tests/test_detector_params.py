@@ -7,7 +7,7 @@ from aruco_slam_amd import capi, synth
 from oracle import pyoracle as orc
 import parity_common as pc
 
-ALT = dict(adaptiveThreshConstant=9.5, minMarkerPerimeterRate=0.08, maxMarkerPerimeterRate=3.0, polygonalApproxAccuracyRate=0.03,
+ALT = dict(perspectiveRemovePixelPerCell=4, adaptiveThreshConstant=9.5, minMarkerPerimeterRate=0.08, maxMarkerPerimeterRate=3.0, polygonalApproxAccuracyRate=0.03,
            minCornerDistanceRate=0.08, minDistanceToBorder=5, minMarkerDistanceRate=0.02, perspectiveRemoveIgnoredMarginPerCell=0.26,
            maxErroneousBitsInBorderRate=0.2, minOtsuStdDev=8.0, errorCorrectionRate=1.0)
 
@@ -51,7 +51,7 @@ def test_parameters_change_the_result():
     assert len(ctx.get_slot_detections(0)[0]) == 3
 
 
-@pytest.mark.parametrize("bad", [dict(adaptiveThreshWinSizeMax=33), dict(perspectiveRemovePixelPerCell=4), dict(markerBorderBits=2),
+@pytest.mark.parametrize("bad", [dict(adaptiveThreshWinSizeMax=33), dict(perspectiveRemovePixelPerCell=12), dict(markerBorderBits=2),
                                  dict(doCornerRefinement=1, cornerRefinementWinSize=9), dict(maxMarkerPerimeterRate=6.0), dict(polygonalApproxAccuracyRate=0.0)])
 def test_compiled_in_or_invalid_values_are_refused(bad):
     ctx = capi.Context(max_rows=64, max_cols=64, max_batch=1, persistent_waves=4, max_landmarks=16)
