@@ -436,7 +436,9 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     if (hipSetDevice(init->device_id) != hipSuccess) return ASLAM_E_NO_DEVICE;
     aslam_ctx* c = new aslam_ctx();
     c->init = *init;
-    if (c->init.cap_starts_per_frame == 0) c->init.cap_starts_per_frame = 1u << 16;
+    // default capacity of the start-candidate list: textured / noisy frames produce a candidate every few pixels
+    if (c->init.cap_starts_per_frame == 0)
+        c->init.cap_starts_per_frame = std::max(1u << 16, (unsigned)((size_t)init->max_rows * init->max_cols / 2));
     if (c->init.cap_contours_per_frame == 0) c->init.cap_contours_per_frame = 1u << 12;
     if (c->init.cap_points_per_frame == 0) c->init.cap_points_per_frame = 1u << 19;
     c->max_batch = init->max_batch;
