@@ -117,6 +117,7 @@ _SIGS = {
     "aslam_sync": (C.c_int, [C.c_void_p]),
     "aslam_get_slot_detections": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _fp, _dp, _dp]),
     "aslam_get_slot_raw_observations": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip, _dp, _dp]),
+    "aslam_get_slot_ekf_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip]),
     "aslam_detect_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                      C.c_int, _ip, _ip, _fp, _dp, _dp]),
     "aslam_export_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -341,6 +342,12 @@ class Context:
         self._ck(self.lib.aslam_get_slot_raw_observations(self.h, int(slot), C.byref(n), _ptr(ids, _ip), _ptr(valid, _ip), _ptr(xyth, _dp), _ptr(R, _dp)))
         k = n.value
         return ids[:k].copy(), valid[:k].copy(), xyth[:k].copy(), R[:k].copy()
+
+    def get_slot_ekf_stats(self, first, count):
+        """count x 4 ints: markers detected, landmarks appended, corrections fused, stationary no-ops of every slot's EKF step"""
+        st = np.zeros((int(count), 4), np.int32)
+        self._ck(self.lib.aslam_get_slot_ekf_stats(self.h, int(first), int(count), _ptr(st, _ip)))
+        return st
 
     def get_landmark_ids(self):
         n = C.c_int()

@@ -23,9 +23,10 @@ using namespace aslam;
 namespace {
 
 enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
-              P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_COUNT };
+              P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_EKF_MID64, P_COUNT };
 const char* kProfNames[P_COUNT] = {"k_threshold", "k_trace", "k_quads", "k_assemble", "k_identify", "k_pose",
-                                   "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update", "k_ekf_mid", "k_ekf_apply"};
+                                   "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update_mfma", "k_ekf_mid", "k_ekf_apply",
+                                   "k_ekf_mid64"};
 
 struct ProfSpan { int id; hipEvent_t a, b; hipStream_t st; };
 
@@ -325,7 +326,7 @@ int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool 
     const bool fast = c->init.max_updates_per_frame <= ekf_fast_max_updates();
     prof_begin(c, P_EKF_PLAN, st);
     launch_ekf_plan(st, c->ekf, c->sp, wl, wr, dt, do_predict ? 1 : 0, c->d_obs + (size_t)slot * kMarkerMax, c->d_nmarkers + slot, c->d_ctr,
-                    c->init.max_updates_per_frame);
+                    c->init.max_updates_per_frame, slot);
     prof_end(c);
     if (fast) {
         prof_begin(c, P_EKF_MID, st);
@@ -335,7 +336,7 @@ int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool 
         launch_ekf_apply(st, c->ekf);
         prof_end(c);
     } else if (c->init.max_updates_per_frame <= ekf_mid_max_updates()) {
-        prof_begin(c, P_EKF_MID, st);
+        prof_begin(c, P_EKF_MID64, st);
         launch_ekf_mid64(st, c->ekf);
         prof_end(c);
         prof_begin(c, P_EKF_T, st);
@@ -457,11 +458,16 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && hipStreamCreateWithPriority(&c->stream_ekf, hipStreamNonBlocking, prio_hi) == hipSuccess;
     {
         // Detection that runs beside an EKF chain is confined to part of every XCD (CU-masked stream), so that the chain's
-        // small dependent kernels always find idle CUs; mask bit i is CU i/8 of XCD i%8 (256 CUs = 8 XCDs x 32).
+        // small dependent kernels always find idle CUs.  Mask bit i is CU i / nxcd of XCD i % nxcd (MI355X: 256 CUs = 8 XCDs
+        // x 32); the layout is only assumed on the device it was measured on (gfx950 with 256 CUs), elsewhere no mask is used.
+        hipDeviceProp_t prop{};
+        const bool known = hipGetDeviceProperties(&prop, init->device_id) == hipSuccess && prop.multiProcessorCount == 256 &&
+                           std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        const int nxcd = 8, per_xcd = 32;
         const int res = init->ekf_reserved_cus_per_xcd == 0 ? 16 : init->ekf_reserved_cus_per_xcd;
-        if (res > 0 && res < 32) {
+        if (known && res > 0 && res < per_xcd) {
             uint32_t mask[8];
-            for (int w = 0; w < 8; w++) { mask[w] = 0; for (int b = 0; b < 32; b++) if ((w * 32 + b) / 8 >= res) mask[w] |= 1u << b; }
+            for (int w = 0; w < 8; w++) { mask[w] = 0; for (int b = 0; b < 32; b++) if ((w * 32 + b) / nxcd >= res) mask[w] |= 1u << b; }
             if (hipExtStreamCreateWithCUMask(&c->stream_part, 8, mask) != hipSuccess) { c->stream_part = nullptr; (void)hipGetLastError(); }
         }
     }
@@ -507,7 +513,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && hipMemset(c->d_nfinal, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_ncand, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_enc, 0, sizeof(double) * 3 * B) == hipSuccess;
-    ok = ok && ekf_alloc(c->ekf, init->max_landmarks) == hipSuccess;
+    ok = ok && ekf_alloc(c->ekf, init->max_landmarks, init->max_batch) == hipSuccess;
     if (!ok) { aslam_destroy(c); return ASLAM_E_NO_DEVICE; }
     *out = c;
     return ASLAM_OK;
@@ -1138,6 +1144,15 @@ int aslam_get_observations(aslam_ctx* c, int* n_out, int* ids, int* idx, int* ac
         if (xyth) { xyth[3 * i] = h[i].z[0]; xyth[3 * i + 1] = h[i].z[1]; xyth[3 * i + 2] = h[i].z[2]; }
         if (Rdiag) std::memcpy(Rdiag + 3 * i, h[i].r, sizeof(double) * 3);
     }
+    return ASLAM_OK;
+}
+
+int aslam_get_slot_ekf_stats(aslam_ctx* c, int first, int count, int* stats) {
+    if (!c || !stats) return fail(c, ASLAM_E_INVALID, "null argument");
+    int r = check_slot_range(c, first, count);
+    if (r) return r;
+    { int rs = sync_streams(c); if (rs) return rs; }
+    HIP_TRY(c, hipMemcpy(stats, c->ekf.d_slot_stat + (size_t)4 * first, sizeof(int) * 4 * count, hipMemcpyDeviceToHost));
     return ASLAM_OK;
 }
 

@@ -45,13 +45,15 @@ struct EkfState {
     double *d_V, *d_Wt, *d_T;          // 3m x ld each, row k contiguous
     double *d_Sv, *d_Sw, *d_alpha, *d_gamma, *d_G, *d_g;
     MapRecord* d_maprec;
+    int* d_slot_stat;                  // per staged slot, written by k_ekf_plan: detections, augments, fused updates, stationary no-ops
+    int max_slots;
 };
 
-hipError_t ekf_alloc(EkfState& E, int max_landmarks);
+hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots);
 void ekf_free(EkfState& E);
 void launch_ekf_predict_only(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt);
 void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int do_predict,
-                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr, int max_m);
+                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr, int max_m, int slot);
 void launch_ekf_mid(hipStream_t st, const EkfState& E);
 void launch_ekf_apply(hipStream_t st, const EkfState& E);
 int ekf_fast_max_updates();
@@ -61,7 +63,6 @@ void launch_ekf_update_mfma(hipStream_t st, const EkfState& E);
 void launch_ekf_gather(hipStream_t st, const EkfState& E);
 void launch_ekf_small(hipStream_t st, const EkfState& E);
 void launch_ekf_T(hipStream_t st, const EkfState& E);
-void launch_ekf_update(hipStream_t st, const EkfState& E);
 void launch_ekf_export_map(hipStream_t st, const EkfState& E);
 
 } // namespace aslam

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_ekf_predict(EkfState E, SlamParams sp, 
 // ---- plan: predict + queue order + augment + update plan (one workgroup) -----------------------------------
 __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, double wl, double wr, double dt, int do_predict,
                                                   const ObsRaw* __restrict__ obs, const unsigned* __restrict__ n_markers,
-                                                  Counters* ctr, int max_m) {
+                                                  Counters* ctr, int max_m, int slot) {
     __shared__ double sH[9], sQ[9], sMu[5];
     __shared__ ObsRaw sObs[kMarkerMax];
     __shared__ LastObs sLast[kMarkerMax];
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
     __shared__ int sOrder[kMarkerMax];         // pop order
     __shared__ int sAction[kMarkerMax];        // per popped observation
     __shared__ int sUpdPos[kMarkerMax];        // position in the fused update list (-1 = none)
-    __shared__ int sNPop, sL, sM, sNNew, sDup, sWaveCnt[2], sCntNew[2], sCntPop[2];
+    __shared__ int sNPop, sL, sM, sNNew, sDup, sWaveCnt[2], sStatCnt[2], sCntNew[2], sCntPop[2];
     __shared__ double sLm[kMarkerMax][3];       // landmark mean per observation slot
     __shared__ double sG[9], sMM[9], sNew[3];
     __shared__ int sDoAug;
@@ -352,7 +352,8 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         // position of every update in the fused list = number of updates popped before it (np <= kMarkerMax = 2 wavefronts)
         const bool upd = tid < np && tid >= nnew && sAction[tid] == 1;
         const unsigned long long bal = __ballot(upd);
-        if (tid < kMarkerMax && (tid & 63) == 0) sWaveCnt[tid >> 6] = __popcll(bal);
+        const unsigned long long balStat = __ballot(tid < np && tid >= nnew && sAction[tid] == 2);
+        if (tid < kMarkerMax && (tid & 63) == 0) { sWaveCnt[tid >> 6] = __popcll(bal); sStatCnt[tid >> 6] = __popcll(balStat); }
         __syncthreads();
         const int before = (tid >= 64 ? sWaveCnt[0] : 0) + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
         const int m = sWaveCnt[0] + sWaveCnt[1];
@@ -404,33 +405,38 @@ __global__ __launch_bounds__(256) void k_ekf_plan(EkfState E, SlamParams sp, dou
         *E.d_npop = np;
         *E.d_L = sL;
         *E.d_m = sM;
+        if (slot >= 0 && slot < E.max_slots) {          // what this frame did (aslam_get_slot_ekf_stats): detections, augments, fused updates, no-ops
+            int* st = E.d_slot_stat + 4 * slot;
+            st[0] = nM; st[1] = sL - L0; st[2] = sM; st[3] = sStatCnt[0] + sStatCnt[1];
+        }
     }
 }
 
-// ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns); grid (columns / 256, update slices) -----------
-__global__ __launch_bounds__(256) void k_ekf_gather(EkfState E) {
-    const int m = *E.d_m;
-    const int N = 3 + 3 * (*E.d_L);
-    const int t = blockIdx.x * 256 + threadIdx.x;
+// ---- gather: V = H Sigma0 (rows), W = Sigma0 H^T (columns) for state column / row t, updates k = slice, slice + nslices, ...
+__device__ __forceinline__ void gather_vw(const EkfState& E, int t, int N, int m, int slice, int nslices) {
     const int ld = E.ld;
-    if (t < N) {
-        const double* col = E.d_sigma + (size_t)t * ld;           // column t: Sigma(:, t)
-        const double c0 = col[0], c1 = col[1], c2 = col[2];
-        const double r0 = E.d_sigma[t], r1 = E.d_sigma[(size_t)ld + t], r2 = E.d_sigma[(size_t)2 * ld + t];   // Sigma(t, 0..2)
-        for (int k = blockIdx.y; k < m; k += gridDim.y) {
-            const UpdRec& u = E.d_upd[k];
-            const int li = u.li;
-            const double l0 = col[li], l1 = col[li + 1], l2 = col[li + 2];
-            const double q0 = E.d_sigma[(size_t)li * ld + t], q1 = E.d_sigma[(size_t)(li + 1) * ld + t],
-                         q2 = E.d_sigma[(size_t)(li + 2) * ld + t];
+    if (t >= N) return;
+    const double* col = E.d_sigma + (size_t)t * ld;           // column t: Sigma(:, t)
+    const double c0 = col[0], c1 = col[1], c2 = col[2];
+    const double r0 = E.d_sigma[t], r1 = E.d_sigma[(size_t)ld + t], r2 = E.d_sigma[(size_t)2 * ld + t];   // Sigma(t, 0..2)
+    for (int k = slice; k < m; k += nslices) {
+        const UpdRec& u = E.d_upd[k];
+        const int li = u.li;
+        const double l0 = col[li], l1 = col[li + 1], l2 = col[li + 2];
+        const double q0 = E.d_sigma[(size_t)li * ld + t], q1 = E.d_sigma[(size_t)(li + 1) * ld + t],
+                     q2 = E.d_sigma[(size_t)(li + 2) * ld + t];
 #pragma unroll
-            for (int a = 0; a < 3; a++) {
-                const double* g = &u.Gxm[a * 6];
-                E.d_V[(size_t)(3 * k + a) * ld + t] = g[0] * c0 + g[1] * c1 + g[2] * c2 + g[3] * l0 + g[4] * l1 + g[5] * l2;
-                E.d_Wt[(size_t)(3 * k + a) * ld + t] = r0 * g[0] + r1 * g[1] + r2 * g[2] + q0 * g[3] + q1 * g[4] + q2 * g[5];
-            }
+        for (int a = 0; a < 3; a++) {
+            const double* g = &u.Gxm[a * 6];
+            E.d_V[(size_t)(3 * k + a) * ld + t] = g[0] * c0 + g[1] * c1 + g[2] * c2 + g[3] * l0 + g[4] * l1 + g[5] * l2;
+            E.d_Wt[(size_t)(3 * k + a) * ld + t] = r0 * g[0] + r1 * g[1] + r2 * g[2] + q0 * g[3] + q1 * g[4] + q2 * g[5];
         }
     }
+}
+
+// grid (columns / 256, update slices)
+__global__ __launch_bounds__(256) void k_ekf_gather(EkfState E) {
+    gather_vw(E, blockIdx.x * 256 + threadIdx.x, 3 + 3 * (*E.d_L), *E.d_m, blockIdx.y, gridDim.y);
 }
 
 // ---- small: replay the sequential recurrences on 3x3 blocks -> G (3m x 3m), g (3m) -------------------------
@@ -704,64 +710,6 @@ __global__ __launch_bounds__(256) void k_ekf_T(EkfState E) {
     }
 }
 
-// ---- Sigma <- Sigma - W T : the one streaming pass over the covariance per frame -----------------------------
-constexpr int UT = 64;        // tile side
-constexpr int UK = 32;        // depth chunk staged through LDS
-
-__global__ __launch_bounds__(256) void k_ekf_update(EkfState E) {
-    __shared__ double sW[UK][UT];
-    __shared__ double sT[UK][UT];
-    const int m = *E.d_m;
-    const int n3 = 3 * m;
-    const int N = 3 + 3 * (*E.d_L);
-    const int ld = E.ld;
-    const int r0 = blockIdx.x * UT, c0 = blockIdx.y * UT;
-    const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6;         // row in tile, group of 16 columns
-    const bool active = m > 0 && r0 < N && c0 < N;                  // uniform per workgroup
-    if (active) {
-        double acc[16], sig[16];
-        const int r = r0 + tr;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {                               // the Sigma tile is fetched while the products are formed
-            const int c = c0 + tc * 16 + j;
-            acc[j] = 0.0;
-            sig[j] = (r < N && c < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
-        }
-        for (int p0 = 0; p0 < n3; p0 += UK) {
-            double tw[8], tt[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int i = threadIdx.x + 256 * k;
-                const int pp = i >> 6, x = i & 63;
-                const int p = p0 + pp;
-                tw[k] = (p < n3 && r0 + x < N) ? E.d_Wt[(size_t)p * ld + r0 + x] : 0.0;
-                tt[k] = (p < n3 && c0 + x < N) ? E.d_T[(size_t)p * ld + c0 + x] : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int i = threadIdx.x + 256 * k;
-                sW[i >> 6][i & 63] = tw[k];
-                sT[i >> 6][i & 63] = tt[k];
-            }
-            __syncthreads();
-            const int pe = min(UK, n3 - p0);
-            for (int pp = 0; pp < pe; pp++) {
-                const double w = sW[pp][tr];
-#pragma unroll
-                for (int j = 0; j < 16; j++) acc[j] += w * sT[pp][tc * 16 + j];
-            }
-            __syncthreads();
-        }
-        if (r < N) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int c = c0 + tc * 16 + j;
-                if (c < N) E.d_sigma[(size_t)c * ld + r] = sig[j] - acc[j];
-            }
-        }
-    }
-}
-
 // =============================================================================================================
 // Fast chain (frames with at most kFastM fused updates): plan -> k_ekf_mid -> k_ekf_apply.
 //   k_ekf_mid   workgroup 0 forms the innovation matrix from the 3+3m observed rows/columns of Sigma0 only
@@ -820,26 +768,7 @@ __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
         const int N = 3 + 3 * (*E.d_L);
         const int ncg = (ld + MIDT - 1) / MIDT;
         const int gb = blockIdx.x - 1;
-        const int t = (gb % ncg) * MIDT + tid;
-        const int slice = gb / ncg, nslices = (gridDim.x - 1) / ncg;
-        if (t < N) {
-            const double* col = E.d_sigma + (size_t)t * ld;
-            const double c0 = col[0], c1 = col[1], c2 = col[2];
-            const double r0 = E.d_sigma[t], r1 = E.d_sigma[(size_t)ld + t], r2 = E.d_sigma[(size_t)2 * ld + t];
-            for (int k = slice; k < m; k += nslices) {
-                const UpdRec& u = E.d_upd[k];
-                const int li = u.li;
-                const double l0 = col[li], l1 = col[li + 1], l2 = col[li + 2];
-                const double q0 = E.d_sigma[(size_t)li * ld + t], q1 = E.d_sigma[(size_t)(li + 1) * ld + t],
-                             q2 = E.d_sigma[(size_t)(li + 2) * ld + t];
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    const double* g = &u.Gxm[a * 6];
-                    E.d_V[(size_t)(3 * k + a) * ld + t] = g[0] * c0 + g[1] * c1 + g[2] * c2 + g[3] * l0 + g[4] * l1 + g[5] * l2;
-                    E.d_Wt[(size_t)(3 * k + a) * ld + t] = r0 * g[0] + r1 * g[1] + r2 * g[2] + q0 * g[3] + q1 * g[4] + q2 * g[5];
-                }
-            }
-        }
+        gather_vw(E, (gb % ncg) * MIDT + tid, N, m, gb / ncg, (gridDim.x - 1) / ncg);
         return;
     }
     // ---- workgroup 0: thread (bi, bj) owns the 3x3 block (bi, bj) of A = H Sigma0 H^T + R in registers ----
@@ -1125,26 +1054,7 @@ __global__ __launch_bounds__(M64T) void k_ekf_mid64(EkfState E) {
         const int N = 3 + 3 * (*E.d_L);
         const int ncg = (ld + M64T - 1) / M64T;
         const int gb = blockIdx.x - 1;
-        const int t = (gb % ncg) * M64T + tid;
-        const int slice = gb / ncg, nslices = (gridDim.x - 1) / ncg;
-        if (t < N) {
-            const double* col = E.d_sigma + (size_t)t * ld;
-            const double c0 = col[0], c1 = col[1], c2 = col[2];
-            const double r0 = E.d_sigma[t], r1 = E.d_sigma[(size_t)ld + t], r2 = E.d_sigma[(size_t)2 * ld + t];
-            for (int k = slice; k < m; k += nslices) {
-                const UpdRec& u = E.d_upd[k];
-                const int li = u.li;
-                const double l0 = col[li], l1 = col[li + 1], l2 = col[li + 2];
-                const double q0 = E.d_sigma[(size_t)li * ld + t], q1 = E.d_sigma[(size_t)(li + 1) * ld + t],
-                             q2 = E.d_sigma[(size_t)(li + 2) * ld + t];
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    const double* g = &u.Gxm[a * 6];
-                    E.d_V[(size_t)(3 * k + a) * ld + t] = g[0] * c0 + g[1] * c1 + g[2] * c2 + g[3] * l0 + g[4] * l1 + g[5] * l2;
-                    E.d_Wt[(size_t)(3 * k + a) * ld + t] = r0 * g[0] + r1 * g[1] + r2 * g[2] + q0 * g[3] + q1 * g[4] + q2 * g[5];
-                }
-            }
-        }
+        gather_vw(E, (gb % ncg) * M64T + tid, N, m, gb / ncg, (gridDim.x - 1) / ncg);
         return;
     }
     // ---- workgroup 0: innovation matrix A = H Sigma0 H^T + R, 3x3 blocks in registers ----
@@ -1410,9 +1320,10 @@ __global__ __launch_bounds__(256) void k_ekf_export_map(EkfState E) {
 // ---- host side -------------------------------------------------------------------------------------------
 template <class T> static hipError_t dalloc(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)); }
 
-hipError_t ekf_alloc(EkfState& E, int max_landmarks) {
+hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots) {
     E = EkfState{};
     E.max_landmarks = max_landmarks;
+    E.max_slots = max_slots;
     E.ld = 3 + 3 * max_landmarks;
     const size_t ld = (size_t)E.ld, n3 = 3 * (size_t)kMarkerMax;
     hipError_t e;
@@ -1439,6 +1350,8 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks) {
     A(dalloc(&E.d_G, n3 * n3));
     A(dalloc(&E.d_g, n3));
     A(dalloc(&E.d_maprec, (size_t)max_landmarks));
+    A(dalloc(&E.d_slot_stat, (size_t)4 * max_slots));
+    A(hipMemset(E.d_slot_stat, 0, (size_t)4 * max_slots * sizeof(int)));
     // ArucoSlam::ArucoSlam (aruco_slam.cpp:13-18): mu = 0 (3), sigma = 0 (3x3), empty map
     A(hipMemset(E.d_mu, 0, ld * sizeof(double)));
     A(hipMemset(E.d_sigma, 0, ld * ld * sizeof(double)));
@@ -1456,7 +1369,7 @@ void ekf_free(EkfState& E) {
     hipFree(E.d_mu); hipFree(E.d_sigma); hipFree(E.d_L); hipFree(E.d_id2idx); hipFree(E.d_idx2id); hipFree(E.d_last); hipFree(E.d_lastNext);
     hipFree(E.d_nlast); hipFree(E.d_pop); hipFree(E.d_npop); hipFree(E.d_upd); hipFree(E.d_m); hipFree(E.d_V); hipFree(E.d_Wt);
     hipFree(E.d_T); hipFree(E.d_Sv); hipFree(E.d_Sw); hipFree(E.d_alpha); hipFree(E.d_gamma); hipFree(E.d_G); hipFree(E.d_g);
-    hipFree(E.d_maprec);
+    hipFree(E.d_maprec); hipFree(E.d_slot_stat);
     E = EkfState{};
 }
 
@@ -1464,8 +1377,8 @@ void launch_ekf_predict_only(hipStream_t st, const EkfState& E, const SlamParams
     hipLaunchKernelGGL(k_ekf_predict, dim3(1), dim3(256), 0, st, E, sp, wl, wr, dt);
 }
 void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int do_predict,
-                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr, int max_m) {
-    hipLaunchKernelGGL(k_ekf_plan, dim3(1), dim3(256), 0, st, E, sp, wl, wr, dt, do_predict, obs, n_markers, ctr, max_m);
+                     const ObsRaw* obs, const unsigned* n_markers, Counters* ctr, int max_m, int slot) {
+    hipLaunchKernelGGL(k_ekf_plan, dim3(1), dim3(256), 0, st, E, sp, wl, wr, dt, do_predict, obs, n_markers, ctr, max_m, slot);
 }
 void launch_ekf_gather(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_gather, dim3((E.ld + 255) / 256, 32), dim3(256), 0, st, E);
@@ -1475,10 +1388,6 @@ void launch_ekf_small(hipStream_t st, const EkfState& E) {
 }
 void launch_ekf_T(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_T, dim3((E.ld + TC - 1) / TC, (3 * kMarkerMax + TR - 1) / TR), dim3(256), 0, st, E);
-}
-void launch_ekf_update(hipStream_t st, const EkfState& E) {
-    const int t = (E.ld + UT - 1) / UT;
-    hipLaunchKernelGGL(k_ekf_update, dim3(t, t), dim3(256), 0, st, E);
 }
 void launch_ekf_mid(hipStream_t st, const EkfState& E) {
     const int ncg = (E.ld + MIDT - 1) / MIDT;

@@ -105,15 +105,35 @@ class SceneConfig:
     r2c: tuple = (0.0, 0.0)
     max_yaw_deg: float = 25.0
     seed: int = 1
+    # cv::aruco::DetectorParameters fields that differ from the OpenCV 3.2.0 defaults for this scene (applied to the library
+    # AND to the oracle by whoever drives the scene: apply_detector())
+    detector: dict = field(default_factory=dict)
 
 
 CONFIGS = {
     # BASELINE.json configs[0..2]; cfg1 uses 3 panels of 4 (12 landmarks) — see DESIGN.md
     "cfg1": SceneConfig(rows=480, cols=640, f=450.0, grid=(2, 2), n_panels=3, col_spacing=0.9, row_spacing=0.7),
     "cfg2": SceneConfig(),
+    # cfg3 packs 50 markers of ~125 px into one 1080p frame and needs 1000 of the 1023 usable DICT_ARUCO_ORIGINAL ids.  Two
+    # detector settings differ from the 3.2.0 defaults, both measured on the oracle over the whole lap:
+    #  * polygonalApproxAccuracyRate 0.03 (the OpenCV >= 3.3 default): with 0.05 the INNER contour of the black border of
+    #    ~8 % of the ids approximates to a quad that is longer than the outer contour, and _filterTooCloseCandidates then
+    #    keeps it instead of the marker (43..49 of 50 markers found in 94 of 320 frames);
+    #  * doCornerRefinement: with integer corners ~2 % of the observations at this marker size exceed the reference's
+    #    covariance gate ||R||_F <= 1 (aruco_slam.cpp:367; R_x = R_y = 100), i.e. most frames would fuse 47..49 updates, not 50.
     "cfg3": SceneConfig(rows=1080, cols=1920, f=1000.0, grid=(10, 5), n_panels=20, col_spacing=0.36, row_spacing=0.34,
-                        tz_far=2.3, tz_near=2.0, max_yaw_deg=20.0),
+                        tz_far=2.3, tz_near=2.0, max_yaw_deg=20.0, seed=2,
+                        detector={"polygonalApproxAccuracyRate": 0.03, "doCornerRefinement": 1}),
 }
+
+
+def apply_detector(cfg, ctx=None, oracle=None):
+    """install cfg.detector on a capi.Context and / or an oracle (module pyoracle or a pyoracle.Slam)"""
+    if cfg.detector:
+        if ctx is not None:
+            ctx.set_detector_params(**cfg.detector)
+        if oracle is not None:
+            oracle.set_detector_params(**cfg.detector)
 
 
 class PanelWorld:

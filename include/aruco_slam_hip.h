@@ -142,6 +142,10 @@ int aslam_sync(aslam_ctx* ctx);
 /* per-slot results of the last aslam_run_staged */
 int aslam_get_slot_detections(aslam_ctx* ctx, int slot, int* M, int* ids, float* corners, double* rvecs, double* tvecs);
 int aslam_get_slot_raw_observations(aslam_ctx* ctx, int slot, int* n, int* ids, int* valid, double* xyth, double* Rdiag);
+/* what the EKF step of each slot in [first, first + count) did, 4 ints per slot: markers detected, landmarks appended
+ * (aruco_slam.cpp:208-260), corrections fused (:108-207) and "stationary" no-ops (:192-198).  Lets a caller assert per frame
+ * that no observation was lost to the range / covariance gates (aruco_slam.cpp:327-333, :367-368). */
+int aslam_get_slot_ekf_stats(aslam_ctx* ctx, int first, int count, int* stats);
 
 /* ---- what the node publishes (aruco_slam_node.cpp:99-118), as plain data for the adapter to wrap in ROS messages ----
  * aslam_get_pose_msg = ArucoSlam::toRosPose (aruco_slam.cpp:378-410): frame "world", z = 0.1, yaw-only quaternion

@@ -69,6 +69,7 @@ def run_slam_sequence(cfg, n_frames, batch, literal, noise_amp=2, per_frame_chec
     ctx.set_camera(w.K, D)
     o = orc.Slam(r2c_tx=cfg.r2c[0], r2c_ty=cfg.r2c[1], literal=literal)
     o.set_camera(w.K, D)
+    synth.apply_detector(cfg, ctx, o)
     t_now = 0.0
     stats = dict(frames=0, updates=0, augments=0, stationary=0, max_mu=0.0, max_sigma=0.0)
     for f0 in range(0, n_frames, batch):
@@ -95,6 +96,12 @@ def run_slam_sequence(cfg, n_frames, batch, literal, noise_amp=2, per_frame_chec
             assert np.array_equal(ox, gx), "landmark indices differ"
             assert np.array_equal(oa, ga), "update/augment/stationary decisions differ"
             assert np.allclose(oz, gz, rtol=POSE_RTOL, atol=1e-9)
+            # observe_covariance_ of ArucoSlam::CalculateCovariance (aruco_slam.cpp:437-471), directly: diag(e R_x + 1e-2, ...)
+            oRd = np.stack([oR[:, k, k] for k in range(3)], -1) if len(oR) else np.zeros((0, 3))
+            assert len(oR) == 0 or np.all(oR == oRd[:, :, None] * np.eye(3)), "the reference's observation covariance is diagonal"
+            assert np.allclose(oRd, gR, rtol=POSE_RTOL, atol=1e-12), f"observation covariance differs by {np.abs(oRd - gR).max()}"
+            st = ctx.get_slot_ekf_stats(first + cnt - 1, 1)[0]
+            assert st[1] == int((ga == 0).sum()) and st[2] == int((ga == 1).sum()) and st[3] == int((ga == 2).sum()), "per-slot EKF stats differ"
             mu_o, S_o = o.get_state()
             mu_g, S_g = ctx.get_state()
             assert mu_o.shape == mu_g.shape, "state size differs"

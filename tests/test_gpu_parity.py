@@ -24,13 +24,18 @@ def test_detector_stage_parity_full_size(name):
     ctx = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=B, max_landmarks=16)
     D = np.zeros(5)
     ctx.set_camera(w.K, D)
-    frs = [w.frame(i * (w.frames_per_panel // 2 + 1)) for i in range(B)]
-    imgs = [ctx.synth_render(i, cfg.rows, cfg.cols, w.K, fr.ids, fr.poses, noise_amp=3, seed=10 + i) for i, fr in enumerate(frs)]
-    ctx.run_staged(0, B, with_ekf=False)
-    ctx.sync()
-    for i in range(B):
-        ids, corners, rv, tv = pc.check_stages(ctx, i, imgs[i], expect_ids=frs[i].ids)
-        pc.check_poses(ids, corners, rv, tv, w.K, D)
+    synth.apply_detector(cfg, ctx, orc)              # cfg3 runs its own detector profile (aruco_slam_amd/synth.py)
+    try:
+        frs = [w.frame(i * (w.frames_per_panel // 2 + 1)) for i in range(B)]
+        imgs = [ctx.synth_render(i, cfg.rows, cfg.cols, w.K, fr.ids, fr.poses, noise_amp=2, seed=i * (w.frames_per_panel // 2 + 1))
+                for i, fr in enumerate(frs)]
+        ctx.run_staged(0, B, with_ekf=False)
+        ctx.sync()
+        for i in range(B):
+            ids, corners, rv, tv = pc.check_stages(ctx, i, imgs[i], expect_ids=frs[i].ids)
+            pc.check_poses(ids, corners, rv, tv, w.K, D)
+    finally:
+        orc.set_detector_params()
 
 
 def test_detector_bgr_input_and_distortion():
@@ -164,12 +169,41 @@ def test_export_map_records():
     assert np.allclose(rec["S"][0].reshape(3, 3), S[3:6, 3:6])
 
 
-def test_cfg3_general_chain_50_markers():
-    """BASELINE config 3 (1920x1080, 50 markers/frame): more than 24 fused updates per frame -> general 5-kernel EKF chain"""
+def test_cfg3_medium_chain_50_markers():
+    """BASELINE config 3 (1920x1080, 50 markers/frame): 25..64 fused updates per frame -> the medium EKF chain"""
     cfg = synth.CONFIGS["cfg3"]
     stats, ctx, o = pc.run_slam_sequence(cfg, 20, batch=10, literal=False, ctx_kwargs=dict(max_updates_per_frame=64))
     assert stats["landmarks"] == 100                      # two panels of 50 entered the map
     assert stats["max_sigma"] < pc.TIGHT
+
+
+def test_cfg3_full_workload_1000_landmarks_50_updates():
+    """BASELINE config 3 AS STATED, end to end: the 1920x1080 stream until the map holds 1000 landmarks (one lap through the
+    augment path), then frames that fuse 50 corrections each at N = 3003; ids / corners per frame, pop order, observation
+    covariances and mu / Sigma against the oracle (rank-3 sequential form) after every batch"""
+    cfg = synth.CONFIGS["cfg3"]
+    w = synth.PanelWorld(cfg)
+    n = w.lap_length() + 12
+    stats, ctx, o = pc.run_slam_sequence(cfg, n, batch=16, literal=False, ctx_kwargs=dict(max_updates_per_frame=64))
+    assert stats["landmarks"] == 1000 and stats["augments"] == 1000
+    mu, S = ctx.get_state()
+    assert mu.size == 3003
+    st = ctx.get_slot_ekf_stats(0, 12)                    # the last batch: second lap, every marker already mapped
+    assert (st[:, 0] == 50).all() and (st[:, 2] == 50).all() and (st[:, 1] == 0).all(), st.tolist()
+    assert stats["max_sigma"] < pc.TIGHT
+    assert np.abs(S - S.T).max() <= 1e-9 * np.abs(S).max() and (np.diag(S) > 0).all()
+
+
+def test_result_surface_and_persistence_on_the_device(tmp_path):
+    """SURVEY §8 f1 / f4 on the real library: toRosPose scatter (aruco_slam.cpp:399-407), the marker arrays (:265-281,
+    :336-347), state save / load and the map.txt loader - the bodies of tests/test_host_surface.py"""
+    import test_host_surface as ths
+    ran = ths.make_ran()
+    ths.test_pose_message(ran)
+    ths.test_map_markers(ran)
+    ths.test_detected_markers(ran)
+    ths.test_state_round_trip_through_a_file(ran, tmp_path)
+    ths.test_map_file_loader_follows_the_reference_rules(tmp_path)
 
 
 def test_cfg5_detect_batch_64_frames():

@@ -24,6 +24,10 @@ def quat_matrix(q):
 
 @pytest.fixture
 def ran():
+    return make_ran()
+
+
+def make_ran():
     cfg = synth.CONFIGS["cfg1"]
     w = synth.PanelWorld(cfg)
     q_r2c = np.array([0.5, -0.5, 0.5, -0.5])                      # optical -> base_link style rotation (x, y, z, w)
