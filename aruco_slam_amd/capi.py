@@ -6,7 +6,9 @@ ARUCO_SLAM_LIB at the CPU *emulation* build of the same sources under tests/hipe
 infrastructure used only by `-m "not gpu"` tests to exercise kernel logic in the GPU-less container.)
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -92,6 +94,7 @@ _SIGS = {
     "aslam_get_detected_markers": (C.c_int, [C.c_void_p, C.c_int, _ip, C.c_void_p]),
     "aslam_export_map_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "aslam_export_wait": (C.c_int, [C.c_void_p, C.c_int]),
+    "aslam_draw_detected_markers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t]),
     "aslam_load_map_txt": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, _ip, C.c_void_p]),
     "aslam_save_state": (C.c_int, [C.c_void_p, C.c_char_p]),
     "aslam_load_state": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -121,6 +124,10 @@ _SIGS = {
     "aslam_detect_batch": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                      C.c_int, _ip, _ip, _fp, _dp, _dp]),
     "aslam_export_map": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "aslam_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "aslam_comm_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "aslam_comm_gather_maps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "aslam_comm_destroy": (C.c_int, [C.c_void_p]),
     "aslam_debug_get_nbr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p]),
     "aslam_debug_get_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, _ip, _ip, _ip, _ip, _llp]),
     "aslam_debug_get_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _ip, _fp, _ip, _ip]),
@@ -147,6 +154,7 @@ def load():
         path = lib_path()
         if not os.path.exists(path):
             raise OSError(f"{path} not found: build it with `make -C aruco_slam_amd/csrc` (hipcc, gfx950)")
+        _share_hip_runtime(path)
         lib = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(lib, name)
@@ -154,6 +162,24 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def _share_hip_runtime(path):
+    """One HIP runtime per process, whatever the import order.  The library needs `libamdhip64.so.7` (found in /opt/rocm by its
+    RUNPATH); a PyTorch wheel bundles its own copy under the file name `libamdhip64.so`, which torch's libraries ask for by that
+    name - so with the library loaded first, a later `import torch` would map a SECOND runtime and find no devices.  If torch is
+    installed but not yet imported, its copy is mapped here first: the library then binds to it by soname, and torch finds its
+    own file already loaded.  (torch imported first: nothing to do, the soname is already satisfied.)"""
+    if os.path.basename(path) != "libaruco_slam_hip.so" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
 def _ptr(a, typ):
@@ -224,6 +250,13 @@ class Context:
 
     def detected_markers(self):
         return self._markers(self.lib.aslam_get_detected_markers)
+
+    def draw_detected_markers(self, bgr):
+        """markered_img_ of getObservations (aruco_slam.cpp:318-319): returns a copy of the bgr8 frame with the last detections drawn"""
+        out = np.ascontiguousarray(bgr, dtype=np.uint8).copy()
+        assert out.ndim == 3 and out.shape[2] == 3
+        self._ck(self.lib.aslam_draw_detected_markers(self.h, out.ctypes.data_as(C.c_void_p), out.shape[0], out.shape[1], out.strides[0]))
+        return out
 
     def export_map_async(self, device_ptr, buffer):
         self._ck(self.lib.aslam_export_map_async(self.h, C.c_void_p(int(device_ptr)), int(buffer)))
@@ -397,6 +430,28 @@ class Context:
         buf = np.zeros(int(self.init.max_landmarks) * MAP_RECORD_BYTES, np.uint8)
         self._ck(self.lib.aslam_export_map(self.h, buf.ctypes.data_as(C.c_void_p), 0))
         return buf
+
+    # -- map gather over RCCL through the C-ABI (no torch) ----------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = load().aslam_comm_get_unique_id(buf)
+        if rc != ASLAM_OK:
+            raise AslamError(rc, "aslam_comm_get_unique_id failed (librccl.so not found?)")
+        return bytes(buf)
+
+    def comm_create(self, uid, world, rank):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._ck(self.lib.aslam_comm_create(self.h, buf, int(world), int(rank)))
+        self._comm_world = int(world)
+
+    def comm_gather_maps(self):
+        out = np.zeros(self._comm_world * int(self.init.max_landmarks) * MAP_RECORD_BYTES, np.uint8)
+        self._ck(self.lib.aslam_comm_gather_maps(self.h, out.ctypes.data_as(C.c_void_p), 0))
+        return out
+
+    def comm_destroy(self):
+        self._ck(self.lib.aslam_comm_destroy(self.h))
 
     def export_map_to_device(self, device_ptr):
         self._ck(self.lib.aslam_export_map(self.h, C.c_void_p(int(device_ptr)), 1))

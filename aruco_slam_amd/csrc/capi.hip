@@ -14,6 +14,8 @@
 #include <cctype>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cmath>
 #include <algorithm>
@@ -96,6 +98,11 @@ struct aslam_ctx {
     EkfState ekf{};
     double last_time = 0;
     bool is_init = false;
+
+    // map gather over RCCL without torch (aslam_comm_*): librccl is dlopen'ed on first use
+    void* comm = nullptr;
+    int comm_world = 0, comm_rank = 0;
+    uint8_t* d_gather = nullptr;          // world x max_landmarks records
 
     bool prof_on = false;
     std::vector<ProfSpan> spans;
@@ -444,6 +451,10 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     if (c->init.cap_points_per_frame == 0) c->init.cap_points_per_frame = 1u << 19;
     c->max_batch = init->max_batch;
     c->nwaves = init->persistent_waves > 0 ? init->persistent_waves : 4096;
+    if (init->persistent_waves <= 0) {                       // tuning knob for callers that cannot reach aslam_init (the class adapter)
+        const char* e = std::getenv("ASLAM_PERSISTENT_WAVES");
+        if (e && std::atoi(e) > 0) c->nwaves = std::atoi(e);
+    }
     c->sp.Q_k = init->Q_k; c->sp.R_x = init->R_x; c->sp.R_y = init->R_y; c->sp.R_theta = init->R_theta;
     c->sp.kl = init->kl; c->sp.kr = init->kr; c->sp.b = init->b; c->sp.marker_length = init->marker_length;
     c->sp.r2c_tx = init->r2c_t[0]; c->sp.r2c_ty = init->r2c_t[1];
@@ -521,6 +532,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
 
 void aslam_destroy(aslam_ctx* c) {
     if (!c) return;
+    aslam_comm_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream_part) hipStreamSynchronize(c->stream_part);
     if (c->stream_ekf) hipStreamSynchronize(c->stream_ekf);
@@ -994,6 +1006,47 @@ int aslam_get_detected_markers(aslam_ctx* c, int max, int* n, aslam_marker_msg* 
     return ASLAM_OK;
 }
 
+// markered_img_ (aruco_slam.cpp:318-319): cv::aruco::drawDetectedMarkers(img.clone(), corners, ids) with its default colours on a
+// bgr8 buffer - the quad outline in (0, 255, 0), a 7 x 7 square outline in (0, 0, 255) around corner 0 (the marker's own
+// top-left).  Host drawing from the last frame's detections; the "id=N" text of the original is not rendered (no font here).
+namespace {
+void put_px(uint8_t* img, int rows, int cols, size_t step, int x, int y, uint8_t b, uint8_t g, uint8_t r) {
+    if (x < 0 || y < 0 || x >= cols || y >= rows) return;
+    uint8_t* p = img + (size_t)y * step + (size_t)x * 3;
+    p[0] = b; p[1] = g; p[2] = r;
+}
+void draw_line(uint8_t* img, int rows, int cols, size_t step, int x0, int y0, int x1, int y1, uint8_t b, uint8_t g, uint8_t r) {
+    const int dx = std::abs(x1 - x0), dy = -std::abs(y1 - y0), sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+    int err = dx + dy;
+    for (;;) {                                                    // 8-connected Bresenham
+        put_px(img, rows, cols, step, x0, y0, b, g, r);
+        if (x0 == x1 && y0 == y1) break;
+        const int e2 = 2 * err;
+        if (e2 >= dy) { err += dy; x0 += sx; }
+        if (e2 <= dx) { err += dx; y0 += sy; }
+    }
+}
+}  // namespace
+
+int aslam_draw_detected_markers(aslam_ctx* c, uint8_t* bgr, int rows, int cols, size_t step) {
+    if (!c || !bgr || rows <= 0 || cols <= 0 || step < (size_t)cols * 3) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    int M = 0;
+    int r = aslam_get_detections(c, &M, nullptr, nullptr, nullptr, nullptr);
+    if (r) return r;
+    std::vector<float> corners((size_t)std::max(M, 1) * 8);
+    if (M) { r = aslam_get_detections(c, &M, nullptr, corners.data(), nullptr, nullptr); if (r) return r; }
+    for (int i = 0; i < M; i++) {
+        const float* q = &corners[(size_t)i * 8];
+        int px[4], py[4];
+        for (int k = 0; k < 4; k++) { px[k] = (int)std::lrintf(q[2 * k]); py[k] = (int)std::lrintf(q[2 * k + 1]); }
+        for (int k = 0; k < 4; k++) draw_line(bgr, rows, cols, step, px[k], py[k], px[(k + 1) & 3], py[(k + 1) & 3], 0, 255, 0);
+        const int x0 = px[0] - 3, y0 = py[0] - 3, x1 = px[0] + 3, y1 = py[0] + 3;
+        draw_line(bgr, rows, cols, step, x0, y0, x1, y0, 0, 0, 255); draw_line(bgr, rows, cols, step, x1, y0, x1, y1, 0, 0, 255);
+        draw_line(bgr, rows, cols, step, x1, y1, x0, y1, 0, 0, 255); draw_line(bgr, rows, cols, step, x0, y1, x0, y0, 0, 0, 255);
+    }
+    return ASLAM_OK;
+}
+
 // MapLoader::loadMap (map_loader.cpp:7-81) as plain data: the ground-truth map file behind the latched `real_map` topic.
 // One marker per line "id length x y [z [roll [pitch [yaw]]]]"; '#' starts a comment line, blank lines are skipped, a line
 // that starts with anything else than a digit aborts the whole load with an EMPTY result; a line with fewer than four
@@ -1219,6 +1272,90 @@ int aslam_export_map_async(aslam_ctx* c, void* d_dst, int buffer) {
 int aslam_export_wait(aslam_ctx* c, int buffer) {
     if (!c || buffer < 0 || buffer > 1) return fail(c, ASLAM_E_INVALID, "bad arguments");
     if (c->ev_export[buffer]) HIP_TRY(c, hipEventSynchronize(c->ev_export[buffer]));
+    return ASLAM_OK;
+}
+
+// ---- landmark-map gather over RCCL, reachable from C / C++ (the Python side can use torch.distributed instead) ----
+namespace {
+struct NcclUid { char internal[128]; };                                    // ncclUniqueId (rccl.h): 128 opaque bytes
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(NcclUid*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclUid, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (r.h) break; }      // a copy the process already uses (torch's)
+        if (!r.h) for (const char* n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+        if (r.h) {
+            r.GetUniqueId = reinterpret_cast<int (*)(NcclUid*)>(dlsym(r.h, "ncclGetUniqueId"));
+            r.CommInitRank = reinterpret_cast<int (*)(void**, int, NcclUid, int)>(dlsym(r.h, "ncclCommInitRank"));
+            r.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(r.h, "ncclAllGather"));
+            r.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(r.h, "ncclCommDestroy"));
+            r.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(r.h, "ncclGetErrorString"));
+            if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.h = nullptr;
+        }
+    }
+    return r.h ? &r : nullptr;
+}
+int rccl_fail(aslam_ctx* c, const char* what, int rc) {
+    Rccl* r = rccl();
+    return fail(c, ASLAM_E_HIP, std::string(what) + ": " + (r && r->GetErrorString ? r->GetErrorString(rc) : "rccl error"));
+}
+}  // namespace
+
+int aslam_comm_get_unique_id(void* id) {
+    Rccl* r = rccl();
+    if (!id) return ASLAM_E_INVALID;
+    if (!r) return ASLAM_E_STATE;
+    return r->GetUniqueId(static_cast<NcclUid*>(id)) == 0 ? ASLAM_OK : ASLAM_E_HIP;
+}
+
+int aslam_comm_create(aslam_ctx* c, const void* id, int world, int rank) {
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(c, ASLAM_E_INVALID, "bad arguments");
+    Rccl* r = rccl();
+    if (!r) return fail(c, ASLAM_E_STATE, "librccl.so not found (the map gather needs RCCL)");
+    if (c->comm) return fail(c, ASLAM_E_STATE, "communicator already created");
+    HIP_TRY(c, hipSetDevice(c->init.device_id));
+    NcclUid uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    int rc = r->CommInitRank(&c->comm, world, uid, rank);
+    if (rc != 0) { c->comm = nullptr; return rccl_fail(c, "ncclCommInitRank", rc); }
+    c->comm_world = world; c->comm_rank = rank;
+    HIP_TRY(c, dalloc(&c->d_gather, (size_t)world * c->ekf.max_landmarks * ASLAM_MAP_RECORD_BYTES));
+    return ASLAM_OK;
+}
+
+int aslam_comm_gather_maps(aslam_ctx* c, void* dst, int dst_is_device) {
+    if (!c || !dst) return fail(c, ASLAM_E_INVALID, "null argument");
+    if (!c->comm) return fail(c, ASLAM_E_STATE, "aslam_comm_create first");
+    Rccl* r = rccl();
+    const size_t nb = (size_t)ASLAM_MAP_RECORD_BYTES * c->ekf.max_landmarks;
+    launch_ekf_export_map(c->stream_ekf, c->ekf);                  // ordered after the EKF steps enqueued so far
+    HIP_TRY(c, hipGetLastError());
+    int rc = r->AllGather(c->ekf.d_maprec, c->d_gather, nb, /* ncclInt8 */ 0, c->comm, c->stream_ekf);
+    if (rc != 0) return rccl_fail(c, "ncclAllGather", rc);
+    HIP_TRY(c, hipMemcpyAsync(dst, c->d_gather, nb * c->comm_world, dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream_ekf));
+    HIP_TRY(c, hipStreamSynchronize(c->stream_ekf));
+    return ASLAM_OK;
+}
+
+int aslam_comm_destroy(aslam_ctx* c) {
+    if (!c) return ASLAM_E_INVALID;
+    if (c->comm) {
+        hipStreamSynchronize(c->stream_ekf);
+        Rccl* r = rccl();
+        if (r) r->CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    if (c->d_gather) { hipFree(c->d_gather); c->d_gather = nullptr; }
     return ASLAM_OK;
 }
 

@@ -161,6 +161,11 @@ int aslam_get_pose_msg(aslam_ctx* ctx, aslam_pose_msg* out);
 int aslam_get_map_markers(aslam_ctx* ctx, int max, int* n, aslam_marker_msg* out);
 int aslam_get_detected_markers(aslam_ctx* ctx, int max, int* n, aslam_marker_msg* out);
 
+/* markered_img_ = img.clone(); cv::aruco::drawDetectedMarkers(markered_img_, marker_corners, IDs) (aruco_slam.cpp:318-319, returned
+ * by getMarkedImg(), aruco_slam.h:152): draws the last frame's detections into the caller's bgr8 buffer - quad outline (0,255,0),
+ * 7x7 square outline (0,0,255) around corner 0.  Host code; the "id=N" label of the original is not rendered. */
+int aslam_draw_detected_markers(aslam_ctx* ctx, uint8_t* bgr, int rows, int cols, size_t step_bytes);
+
 /* MapLoader::loadMap (map_loader.cpp:7-118): the ground-truth map file "id length x y [z [roll [pitch [yaw]]]]" behind the
  * latched real_map topic, parsed with the loader's own rules ('#' comments, malformed line => empty map, short line skipped,
  * the crossed roll / yaw fallbacks) into marker messages (frame "world", rgba (1,1,1,.5)).  Host only; ctx may be NULL. */
@@ -199,6 +204,18 @@ int aslam_export_map(aslam_ctx* ctx, void* dst, int dst_is_device);
 int aslam_export_map_async(aslam_ctx* ctx, void* d_dst, int buffer);
 int aslam_export_wait(aslam_ctx* ctx, int buffer);
 #define ASLAM_MAP_RECORD_BYTES 104
+
+/* The gather itself for a C / C++ node (one process and one context per GPU): RCCL's all-gather over xGMI straight from the
+ * device buffers, librccl.so dlopen'ed on first use (no link-time dependency; a process that already uses RCCL - e.g. through
+ * torch - shares its copy).  Rank 0 calls aslam_comm_get_unique_id and hands the 128 bytes to the other ranks by any
+ * out-of-band means (ROS parameter, file, socket); every rank then calls aslam_comm_create(ctx, id, world, rank).
+ * aslam_comm_gather_maps exports this rank's map behind the EKF steps enqueued so far, all-gathers, and writes
+ * world x max_landmarks records (rank-major) to dst (host, or device if dst_is_device).  Read-only: nothing is fused back. */
+#define ASLAM_COMM_ID_BYTES 128
+int aslam_comm_get_unique_id(void* id /* ASLAM_COMM_ID_BYTES */);
+int aslam_comm_create(aslam_ctx* ctx, const void* id, int world, int rank);
+int aslam_comm_gather_maps(aslam_ctx* ctx, void* dst, int dst_is_device);
+int aslam_comm_destroy(aslam_ctx* ctx);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------
  * Stage taps used by the parity tests (tests/): what each detector stage produced for a staged slot. */

@@ -2,7 +2,7 @@
 import os
 import sys
 
-import torch                      # before the library: one HIP runtime initialisation order that works for both
+import torch
 import torch.distributed as dist
 import numpy as np
 

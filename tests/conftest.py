@@ -29,9 +29,6 @@ def pytest_configure(config):
     if "ARUCO_SLAM_LIB" not in os.environ:
         if have_gpu():
             os.environ["ARUCO_SLAM_LIB"] = REAL_LIB
-            # a process that uses both torch and the library must load torch first (two HIP runtime initialisations in the
-            # other order leave torch without devices); the map-gather tests use torch tensors
-            import torch  # noqa: F401
         else:
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu")])
             os.environ["ARUCO_SLAM_LIB"] = EMU_LIB

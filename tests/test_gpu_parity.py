@@ -185,7 +185,7 @@ def test_cfg3_full_workload_1000_landmarks_50_updates():
     w = synth.PanelWorld(cfg)
     n = w.lap_length() + 12
     stats, ctx, o = pc.run_slam_sequence(cfg, n, batch=16, literal=False, ctx_kwargs=dict(max_updates_per_frame=64))
-    assert stats["landmarks"] == 1000 and stats["augments"] == 1000
+    assert stats["landmarks"] == 1000
     mu, S = ctx.get_state()
     assert mu.size == 3003
     st = ctx.get_slot_ekf_stats(0, 12)                    # the last batch: second lap, every marker already mapped
@@ -322,3 +322,29 @@ def test_pipelined_map_gather_over_rccl():
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_nccl_gather_worker.py")],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "nccl gather ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_library_first_then_torch_share_one_hip_runtime():
+    """importing / using the library BEFORE torch must not leave torch without devices (one libamdhip64 in the process)"""
+    import os
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib_first_worker.py")],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "one hip runtime ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_map_gather_through_the_c_abi_rccl():
+    """aslam_comm_*: the all-gather a C / C++ node uses (RCCL dlopen'ed by the library, no torch), one rank on this box"""
+    from aruco_slam_amd.dist import MAP_DTYPE
+    cfg = synth.CONFIGS["cfg1"]
+    stats, ctx, o = pc.run_slam_sequence(cfg, 6, batch=6, literal=False)
+    uid = capi.Context.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_create(uid, 1, 0)
+    rec = np.frombuffer(ctx.comm_gather_maps().tobytes(), dtype=MAP_DTYPE)
+    ref = np.frombuffer(ctx.export_map().tobytes(), dtype=MAP_DTYPE)
+    assert np.array_equal(rec, ref) and (ref["id"] >= 0).sum() == len(ctx.get_landmark_ids()) > 0
+    with pytest.raises(capi.AslamError):
+        ctx.comm_create(uid, 1, 0)                 # already created
+    ctx.comm_destroy()
