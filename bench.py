@@ -135,21 +135,25 @@ def scene_setup(np, capi, synth, cfg_name, rank, local_rank, args, with_ekf, dow
         ctx.synth_render(i, cfg.rows, cfg.cols, world.K, fr.ids, fr.poses, noise_amp=2, seed=seeds[i], download=False)
     # "the generator must be tuned (and the count asserted) or the EKF silently sees fewer than M updates":
     # frames whose noise realisation costs a marker (detection or a gate) are re-rendered with another seed
-    for attempt in range(8):
+    for attempt in range(10):
         ctx.run_staged(0, lap, with_ekf=False)
         ctx.sync()
-        bad = []
+        bad, prev = [], None
         for i in range(lap):
-            ids, valid, _, _ = ctx.get_slot_raw_observations(i)
+            ids, valid, xyth, _ = ctx.get_slot_raw_observations(i)
+            cur = {int(a): z for a, z in zip(ids, xyth)}
             if len(ids) != world.M or int(valid.sum()) != world.M or sorted(ids.tolist()) != sorted(frames[i].ids.tolist()):
                 bad.append(i)
+            elif prev is not None and any(a in prev and np.linalg.norm(prev[a] - z) < 0.0125 for a, z in cur.items()):
+                bad.append(i)              # would take the reference's "stationary" no-op branch (aruco_slam.cpp:192-198, < 0.01)
+            prev = cur
         if not bad:
             break
         for i in bad:
             seeds[i] += 100003
             ctx.synth_render(i, cfg.rows, cfg.cols, world.K, frames[i].ids, frames[i].poses, noise_amp=2, seed=seeds[i], download=False)
     else:
-        raise SystemExit(f"{cfg_name}: could not qualify frames {bad[:8]} (markers lost to detection or the gates)")
+        raise SystemExit(f"{cfg_name}: could not qualify frames {bad[:8]} (markers lost to detection, the gates or the stationary branch)")
     host = None
     if download:
         host = np.stack([ctx.synth_render(i, cfg.rows, cfg.cols, world.K, frames[i].ids, frames[i].poses, noise_amp=2, seed=seeds[i])
