@@ -144,7 +144,7 @@ def scene_setup(np, capi, synth, cfg_name, rank, local_rank, args, with_ekf, dow
             cur = {int(a): z for a, z in zip(ids, xyth)}
             if len(ids) != world.M or int(valid.sum()) != world.M or sorted(ids.tolist()) != sorted(frames[i].ids.tolist()):
                 bad.append(i)
-            elif prev is not None and any(a in prev and np.linalg.norm(prev[a] - z) < 0.0125 for a, z in cur.items()):
+            elif prev is not None and any(a in prev and np.linalg.norm(prev[a] - z) < 0.0101 for a, z in cur.items()):
                 bad.append(i)              # would take the reference's "stationary" no-op branch (aruco_slam.cpp:192-198, < 0.01)
             prev = cur
         if not bad:
@@ -450,7 +450,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=200, help="frames per step (<= half a lap keeps consecutive steps on disjoint slots)")
+    ap.add_argument("--batch", type=int, default=160, help="frames per step (<= half a lap keeps consecutive steps on disjoint slots)")
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--cpu-sample", type=int, default=240, help="frames handed to the CPU oracle (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per baseline leg")
