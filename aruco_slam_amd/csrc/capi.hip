@@ -8,6 +8,7 @@
 #include "../../include/aruco_slam_hip.h"
 #include <string>
 #include <vector>
+#include <queue>
 #include <cfloat>
 #include <fstream>
 #include <sstream>
@@ -25,10 +26,10 @@ using namespace aslam;
 namespace {
 
 enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
-              P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_EKF_MID64, P_COUNT };
+              P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_EKF_MID64, P_EKF_WIN_CHAIN, P_EKF_WIN_SCAN, P_EKF_WIN_FLUSH, P_COUNT };
 const char* kProfNames[P_COUNT] = {"k_threshold", "k_trace", "k_quads", "k_assemble", "k_identify", "k_pose",
                                    "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update_mfma", "k_ekf_mid", "k_ekf_apply",
-                                   "k_ekf_mid64"};
+                                   "k_ekf_mid64", "k_ekf_win_chain", "k_ekf_win_scan", "k_ekf_win_flush"};
 
 struct ProfSpan { int id; hipEvent_t a, b; hipStream_t st; };
 
@@ -99,6 +100,25 @@ struct aslam_ctx {
     double last_time = 0;
     bool is_init = false;
 
+    // windowed EKF (ekf_window.hip): the observations of a batch come back to the host, which cuts the batch into runs of
+    // frames that fuse the same landmarks; the batch's EKF work is enqueued one call later (or at the next synchronisation),
+    // behind the NEXT batch's detection, so that the detection stream never waits for the host
+    bool win_enabled = true;
+    struct Pending { bool active = false; int first = 0, count = 0, ev = 0; } pend;
+    hipEvent_t ev_obs[2] = {nullptr, nullptr}, ev_idx = nullptr;
+    int ev_obs_next = 0;
+    bool ev_idx_set = false;
+    ObsRaw* h_obs = nullptr;              // pinned: max_batch x kMarkerMax
+    unsigned* h_nm = nullptr;             // pinned: max_batch
+    unsigned char* h_obs_idx = nullptr;   // pinned: max_batch x kWinM, detection index of the j-th popped observation
+    unsigned char* d_obs_idx = nullptr;
+    std::vector<int> m_id2idx;            // host mirror of the id -> landmark table, valid unless mirror_dirty
+    int m_L = 0;
+    struct HostLast { int id; double z[3]; };
+    std::vector<HostLast> m_last;         // host mirror of last_observed_marker_ (NaN z = unset)
+    bool mirror_dirty = true;             // the device planned frames the host could not follow: read the tables back before planning
+    int ekf_lo = 0, ekf_hi = 0;           // union of the slot ranges of EKF work enqueued since the last wait on ev_ekf
+
     // map gather over RCCL without torch (aslam_comm_*): librccl is dlopen'ed on first use
     void* comm = nullptr;
     int comm_world = 0, comm_rank = 0;
@@ -110,6 +130,8 @@ struct aslam_ctx {
     int prof_calls[P_COUNT] = {0};
     double prof_ms[P_COUNT] = {0};
 };
+
+extern "C" int finalize_pending(aslam_ctx* c);      // defined with run_staged below (internal, not part of the C-ABI header)
 
 namespace {
 
@@ -264,7 +286,7 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
     if (!c->have_cam) return fail(c, ASLAM_E_STATE, "camera parameters not set (aslam_set_camera)");
     // the CU-masked stream only pays off while an EKF chain is actually in flight beside this detection; the first batch after
     // a synchronisation gets the whole GPU
-    hipStream_t st = (beside_ekf && c->stream_part && c->ekf_count > 0) ? c->stream_part : c->stream;
+    hipStream_t st = (beside_ekf && c->stream_part && (c->ekf_count > 0 || c->pend.active)) ? c->stream_part : c->stream;
     if (c->last_detect && c->last_detect != st) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_detect, 0));   // slots / work lists are shared
     c->last_detect = st;
     if (wait_before) HIP_TRY(c, hipStreamWaitEvent(st, wait_before, 0));          // frames still in flight on the copy stream
@@ -273,8 +295,8 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
     const bool alias_gray = c->channels == 1;              // staged gray frames are tight: the detector reads them in place
     c->last_first = first;
     c->last_count = count;
-    if (c->ekf_count > 0 && first < c->ekf_first + c->ekf_count && c->ekf_first < first + count) {
-        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_ekf, 0));   // an EKF chain in flight still reads observations of these slots
+    if (c->ekf_count > 0 && first < c->ekf_hi && c->ekf_lo < first + count) {
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_ekf, 0));   // EKF work in flight still reads observations of these slots
         c->ekf_count = 0;
     }
     for (int f0 = first; f0 < first + count; f0 += max_frames_per_call()) {
@@ -371,6 +393,7 @@ int run_ekf_frame(aslam_ctx* c, int slot, double wl, double wr, double dt, bool 
 }
 
 int sync_streams(aslam_ctx* c) {
+    { int r = finalize_pending(c); if (r) return r; }
     if (c->stream_copy) HIP_TRY(c, hipStreamSynchronize(c->stream_copy));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->stream_part) HIP_TRY(c, hipStreamSynchronize(c->stream_part));
@@ -460,6 +483,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     c->sp.r2c_tx = init->r2c_t[0]; c->sp.r2c_ty = init->r2c_t[1];
     c->sp.useful_distance_threshold = init->useful_distance_threshold;
 
+    c->win_enabled = std::getenv("ASLAM_NO_WINDOWS") == nullptr;
     const int B = c->max_batch;
     const size_t px = (size_t)init->max_rows * init->max_cols;
     const size_t pitch = ((size_t)init->max_cols + 63) / 64 * 64;
@@ -475,7 +499,8 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
         const bool known = hipGetDeviceProperties(&prop, init->device_id) == hipSuccess && prop.multiProcessorCount == 256 &&
                            std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
         const int nxcd = 8, per_xcd = 32;
-        const int res = init->ekf_reserved_cus_per_xcd == 0 ? 16 : init->ekf_reserved_cus_per_xcd;
+        // windowed EKF: one chain workgroup, 16 scan workgroups and a tile pass per window instead of three kernels per frame
+        const int res = init->ekf_reserved_cus_per_xcd == 0 ? (c->win_enabled ? 4 : 16) : init->ekf_reserved_cus_per_xcd;
         if (known && res > 0 && res < per_xcd) {
             uint32_t mask[8];
             for (int w = 0; w < 8; w++) { mask[w] = 0; for (int b = 0; b < 32; b++) if ((w * 32 + b) / nxcd >= res) mask[w] |= 1u << b; }
@@ -525,6 +550,13 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && hipMemset(c->d_ncand, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_enc, 0, sizeof(double) * 3 * B) == hipSuccess;
     ok = ok && ekf_alloc(c->ekf, init->max_landmarks, init->max_batch) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_obs[0], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_obs[1], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_idx, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_obs), (size_t)B * kMarkerMax * sizeof(ObsRaw), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_nm), (size_t)B * sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_obs_idx), (size_t)B * kWinM, hipHostMallocDefault) == hipSuccess;
+    ok = ok && dalloc(&c->d_obs_idx, (size_t)B * kWinM) == hipSuccess;
     if (!ok) { aslam_destroy(c); return ASLAM_E_NO_DEVICE; }
     *out = c;
     return ASLAM_OK;
@@ -532,6 +564,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
 
 void aslam_destroy(aslam_ctx* c) {
     if (!c) return;
+    c->pend.active = false;
     aslam_comm_destroy(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->stream_part) hipStreamSynchronize(c->stream_part);
@@ -551,6 +584,12 @@ void aslam_destroy(aslam_ctx* c) {
     for (int h = 0; h < 2; h++) { if (c->ev_up[h]) hipEventDestroy(c->ev_up[h]); if (c->ev_det[h]) hipEventDestroy(c->ev_det[h]); }
     for (int h = 0; h < 2; h++) if (c->ev_export[h]) hipEventDestroy(c->ev_export[h]);
     if (c->h_ring) hipHostFree(c->h_ring);
+    if (c->h_obs) hipHostFree(c->h_obs);
+    if (c->h_nm) hipHostFree(c->h_nm);
+    if (c->h_obs_idx) hipHostFree(c->h_obs_idx);
+    hipFree(c->d_obs_idx);
+    for (int h = 0; h < 2; h++) if (c->ev_obs[h]) hipEventDestroy(c->ev_obs[h]);
+    if (c->ev_idx) hipEventDestroy(c->ev_idx);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->stream_part) hipStreamDestroy(c->stream_part);
     if (c->stream_ekf) hipStreamDestroy(c->stream_ekf);
@@ -599,9 +638,179 @@ int aslam_stage_encoders(aslam_ctx* c, int slot0, int n, const double* wl, const
     return ASLAM_OK;
 }
 
+void note_ekf_range(aslam_ctx* c, int first, int count) {
+    if (c->ekf_count == 0) { c->ekf_lo = first; c->ekf_hi = first + count; }
+    else { c->ekf_lo = std::min(c->ekf_lo, first); c->ekf_hi = std::max(c->ekf_hi, first + count); }
+    c->ekf_first = first;
+    c->ekf_count = count;
+}
+
+int read_mirror(aslam_ctx* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream_ekf));
+    c->m_id2idx.resize(kIdTableSize);
+    HIP_TRY(c, hipMemcpy(c->m_id2idx.data(), c->ekf.d_id2idx, sizeof(int) * kIdTableSize, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&c->m_L, c->ekf.d_L, sizeof(int), hipMemcpyDeviceToHost));
+    int nl = 0;
+    HIP_TRY(c, hipMemcpy(&nl, c->ekf.d_nlast, sizeof(int), hipMemcpyDeviceToHost));
+    nl = std::min(std::max(nl, 0), (int)kMarkerMax);
+    std::vector<LastObs> h(std::max(nl, 1));
+    if (nl) HIP_TRY(c, hipMemcpy(h.data(), c->ekf.d_last, sizeof(LastObs) * nl, hipMemcpyDeviceToHost));
+    c->m_last.resize(nl);
+    for (int i = 0; i < nl; i++) { c->m_last[i].id = h[i].id; for (int k = 0; k < 3; k++) c->m_last[i].z[k] = h[i].z[k]; }
+    c->mirror_dirty = false;
+    return ASLAM_OK;
+}
+
+// The EKF work of the pending batch: the host follows the reference's bookkeeping (checkLandmark, queue order, the
+// "stationary" test, aruco_slam.cpp:92-95, 192-198, 423-435) on the observations read back from the device and cuts the batch
+// into windows = runs of frames that fuse the same landmarks (ekf_window.hip); every other frame, and every frame the host
+// cannot decide (a marker id it does not know: a new landmark; one id twice), takes the per-frame chain, planned on the device.
+int finalize_pending(aslam_ctx* c) {
+    if (!c->pend.active) return ASLAM_OK;
+    const aslam_ctx::Pending p = c->pend;
+    c->pend.active = false;
+    HIP_TRY(c, hipEventSynchronize(c->ev_obs[p.ev]));
+    if (c->mirror_dirty) { int r = read_mirror(c); if (r) return r; }
+    if (c->ev_idx_set) HIP_TRY(c, hipEventSynchronize(c->ev_idx));          // the previous batch's upload has left the pinned rows
+    HIP_TRY(c, hipStreamWaitEvent(c->stream_ekf, c->ev_obs[p.ev], 0));
+    struct Op { int frame; bool predict; WinDesc wd; };                     // wd.K == 0: per-frame chain for `frame`
+    std::vector<Op> ops;
+    WinDesc cur{};
+    cur.K = 0;
+    bool device_plans = false;
+    auto close_window = [&]() {
+        if (cur.K == 0) return;
+        Op o{};
+        if (cur.K == 1) { o.frame = cur.first_slot; o.predict = true; o.wd.K = 0; }      // a lone frame: the per-frame chain is as good
+        else { o.frame = cur.first_slot; o.predict = true; o.wd = cur; }
+        ops.push_back(o);
+        cur.K = 0;
+    };
+    for (int f = p.first; f < p.first + p.count; f++) {
+        const bool predict = c->is_init;            // addEncoder semantics (aruco_slam.cpp:24-29): the very first sample only arms the filter
+        c->is_init = true;
+        const ObsRaw* ob = c->h_obs + (size_t)f * kMarkerMax;
+        const int nM = (int)std::min(c->h_nm[f], (unsigned)kMarkerMax);
+        bool clean = !device_plans;
+        std::vector<std::pair<int, int>> pop;       // (landmark index, detection index) of the observations that pass the gates, pop order
+        int n_new = 0;
+        if (clean) {
+            // obs_.push(ob) in detection order into the reference's own priority queue (aruco_slam.h:85-88, aruco_slam.cpp:369-373):
+            // new markers (index -1) pop first, in libstdc++ heap order, and take the next landmark indices in that order (:256)
+            struct QItem { int idx, det; bool operator<(const QItem& o) const { return idx > o.idx; } };
+            std::priority_queue<QItem> q;
+            std::vector<int> seen;
+            for (int i = 0; i < nM && clean; i++) {
+                if (!ob[i].valid) continue;
+                const int id = ob[i].id;
+                if (id < 0 || id >= kIdTableSize || std::find(seen.begin(), seen.end(), id) != seen.end()) { clean = false; break; }   // one id twice (Q10): device
+                seen.push_back(id);
+                q.push(QItem{c->m_id2idx[id], i});
+            }
+            while (clean && !q.empty()) {
+                QItem it = q.top();
+                q.pop();
+                if (it.idx < 0) {
+                    if (c->m_L >= c->ekf.max_landmarks) { clean = false; break; }        // capacity: reported by the device
+                    it.idx = c->m_L++;
+                    c->m_id2idx[ob[it.det].id] = it.idx;
+                    n_new++;
+                }
+                pop.push_back({it.idx, it.det});
+            }
+        }
+        if (!clean) {
+            close_window();
+            device_plans = true;
+            c->mirror_dirty = true;
+            Op o{};
+            o.frame = f; o.predict = predict; o.wd.K = 0;
+            ops.push_back(o);
+            continue;
+        }
+        // pop order = ascending landmark index (aruco_slam.h:85-88); "stationary" test against last frame's list (:192-198)
+        bool any_stationary = false;
+        std::vector<aslam_ctx::HostLast> nlast(pop.size());
+        for (size_t j = 0; j < pop.size(); j++) {
+            const ObsRaw& o = ob[pop[j].second];
+            bool stationary = false;
+            if ((int)j < n_new) {                                            // augment branch: last_observation_ stays unset (Q3)
+                nlast[j].id = o.id;
+                nlast[j].z[0] = nlast[j].z[1] = nlast[j].z[2] = std::nan("");
+                continue;
+            }
+            for (const aslam_ctx::HostLast& l : c->m_last)
+                if (l.id == o.id) {                                          // std::find: first with the same id
+                    const double d0 = l.z[0] - o.x, d1 = l.z[1] - o.y, d2 = l.z[2] - o.th;
+                    stationary = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2) < 0.01;     // NaN compares false
+                    break;
+                }
+            any_stationary = any_stationary || stationary;
+            nlast[j].id = o.id;
+            if (stationary) { nlast[j].z[0] = nlast[j].z[1] = nlast[j].z[2] = std::nan(""); }
+            else { nlast[j].z[0] = o.x; nlast[j].z[1] = o.y; nlast[j].z[2] = o.th; }
+        }
+        c->m_last.swap(nlast);
+        const int m = (int)pop.size();
+        const bool eligible = predict && n_new == 0 && !any_stationary && m >= 1 && m <= kWinM;
+        if (!eligible) {
+            close_window();
+            Op o{};
+            o.frame = f; o.predict = predict; o.wd.K = 0;
+            ops.push_back(o);
+            continue;
+        }
+        bool same = cur.K > 0 && cur.K < kWinFrames && cur.m == m && f == cur.first_slot + cur.K;
+        for (int j = 0; j < m && same; j++) same = cur.li[j] == 3 + 3 * pop[j].first;
+        if (!same) {
+            close_window();
+            cur.first_slot = f; cur.K = 0; cur.m = m; cur.s = 3 + 3 * m;
+            for (int j = 0; j < m; j++) cur.li[j] = 3 + 3 * pop[j].first;
+        }
+        for (int j = 0; j < m; j++) c->h_obs_idx[(size_t)f * kWinM + j] = (unsigned char)pop[j].second;
+        cur.K++;
+    }
+    close_window();
+    bool any_window = false;
+    for (const Op& o : ops) any_window = any_window || o.wd.K > 0;
+    if (any_window) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_obs_idx + (size_t)p.first * kWinM, c->h_obs_idx + (size_t)p.first * kWinM, (size_t)p.count * kWinM,
+                                  hipMemcpyHostToDevice, c->stream_ekf));
+        HIP_TRY(c, hipEventRecord(c->ev_idx, c->stream_ekf));
+        c->ev_idx_set = true;
+    }
+    for (const Op& o : ops) {
+        if (o.wd.K == 0) {
+            const double* e = &c->enc_host[(size_t)3 * o.frame];
+            int r = run_ekf_frame(c, o.frame, e[0], e[1], e[2], o.predict);
+            if (r) return r;
+        } else {
+            hipStream_t st = c->stream_ekf;
+            prof_begin(c, P_EKF_WIN_CHAIN, st);
+            launch_ekf_win_chain(st, c->ekf, c->sp, o.wd, c->d_obs, c->d_nmarkers, c->d_enc, c->d_obs_idx + (size_t)o.wd.first_slot * kWinM);
+            prof_end(c);
+            prof_begin(c, P_EKF_WIN_SCAN, st);
+            launch_ekf_win_scan(st, c->ekf, o.wd);
+            prof_end(c);
+            prof_begin(c, P_EKF_WIN_FLUSH, st);
+            launch_ekf_win_flush(st, c->ekf, o.wd);
+            prof_end(c);
+            HIP_TRY(c, hipGetLastError());
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_ekf, c->stream_ekf));
+    note_ekf_range(c, p.first, p.count);
+    return ASLAM_OK;
+}
+
 int run_staged(aslam_ctx* c, int first, int count, int with_ekf, hipEvent_t wait_before) {
     int r = check_slot_range(c, first, count);
     if (r) return r;
+    if (with_ekf && c->enc_host.size() < (size_t)3 * (first + count)) return fail(c, ASLAM_E_STATE, "encoders not staged");
+    if (c->pend.active && first < c->pend.first + c->pend.count && c->pend.first < first + count) {
+        r = finalize_pending(c);               // the pending batch still needs the observations in these slots
+        if (r) return r;
+    }
     if (with_ekf != 2) {                       // 2 = EKF only, on observations already present in the slots (tests)
         r = run_detect(c, first, count, with_ekf == 1, wait_before);
         if (r) return r;
@@ -610,21 +819,33 @@ int run_staged(aslam_ctx* c, int first, int count, int with_ekf, hipEvent_t wait
         c->last_detect = c->stream;
         HIP_TRY(c, hipEventRecord(c->ev_detect, c->stream));
     }
-    if (with_ekf) {
-        if (c->enc_host.size() < (size_t)3 * (first + count)) return fail(c, ASLAM_E_STATE, "encoders not staged");
+    if (!with_ekf) return ASLAM_OK;
+    if (!c->win_enabled) {                     // every frame on the per-frame chain, enqueued at once
+        r = finalize_pending(c);
+        if (r) return r;
         HIP_TRY(c, hipStreamWaitEvent(c->stream_ekf, c->ev_detect, 0));
         for (int i = 0; i < count; i++) {
             const double* e = &c->enc_host[(size_t)3 * (first + i)];
-            // addEncoder semantics (aruco_slam.cpp:24-29): the very first sample only arms the filter
-            bool predict = c->is_init;
+            bool predict = c->is_init;         // addEncoder semantics (aruco_slam.cpp:24-29): the very first sample only arms the filter
             c->is_init = true;
             r = run_ekf_frame(c, first + i, e[0], e[1], e[2], predict);
             if (r) return r;
         }
         HIP_TRY(c, hipEventRecord(c->ev_ekf, c->stream_ekf));
-        c->ekf_first = first;
-        c->ekf_count = count;
+        note_ekf_range(c, first, count);
+        return ASLAM_OK;
     }
+    // observations of the batch to the host, behind its detection; the batch's EKF work is enqueued by finalize_pending
+    hipStream_t st = c->last_detect;
+    const int e = c->ev_obs_next;
+    c->ev_obs_next ^= 1;
+    HIP_TRY(c, hipMemcpyAsync(c->h_obs + (size_t)first * kMarkerMax, c->d_obs + (size_t)first * kMarkerMax, (size_t)count * kMarkerMax * sizeof(ObsRaw),
+                              hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemcpyAsync(c->h_nm + first, c->d_nmarkers + first, (size_t)count * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipEventRecord(c->ev_obs[e], st));
+    r = finalize_pending(c);                   // the PREVIOUS batch: its detection has long finished, this one's is already queued
+    if (r) return r;
+    c->pend.active = true; c->pend.first = first; c->pend.count = count; c->pend.ev = e;
     return ASLAM_OK;
 }
 
@@ -821,6 +1042,7 @@ int aslam_add_encoder(aslam_ctx* c, double wl, double wr, double t_now) {
     }
     double dt = t_now - c->last_time;        // aruco_slam.cpp:31-32
     c->last_time = t_now;
+    { int rp = finalize_pending(c); if (rp) return rp; }
     launch_ekf_predict_only(c->stream_ekf, c->ekf, c->sp, wl, wr, dt);
     HIP_TRY(c, hipGetLastError());
     return ASLAM_OK;
@@ -829,7 +1051,10 @@ int aslam_add_encoder(aslam_ctx* c, double wl, double wr, double t_now) {
 int aslam_add_image(aslam_ctx* c, const uint8_t* px, int rows, int cols, int channels, size_t step) {
     if (!c || !px) return fail(c, ASLAM_E_INVALID, "null argument");
     if (!c->is_init) return ASLAM_OK;        // aruco_slam.cpp:84-85: nothing happens before the first encoder message
-    int r = aslam_stage_frames(c, 0, px, 1, rows, cols, channels, step, 0);
+    int r = finalize_pending(c);
+    if (r) return r;
+    c->mirror_dirty = true;                  // planned on the device: the host's copy of the tables is stale afterwards
+    r = aslam_stage_frames(c, 0, px, 1, rows, cols, channels, step, 0);
     if (r) return r;
     r = run_detect(c, 0, 1);
     if (r) return r;
@@ -877,6 +1102,7 @@ int aslam_set_state(aslam_ctx* c, int N, const double* mu, const double* sigma, 
     HIP_TRY(c, hipMemcpy(c->ekf.d_L, &L, sizeof(int), hipMemcpyHostToDevice));
     int zero = 0;
     HIP_TRY(c, hipMemcpy(c->ekf.d_nlast, &zero, sizeof(int), hipMemcpyHostToDevice));
+    c->mirror_dirty = true;
     return ASLAM_OK;
 }
 
@@ -1251,6 +1477,7 @@ int aslam_detect_batch(aslam_ctx* c, const uint8_t* frames, int nframes, int row
 
 int aslam_export_map(aslam_ctx* c, void* dst, int dst_is_device) {
     if (!c || !dst) return fail(c, ASLAM_E_INVALID, "null argument");
+    { int rp = finalize_pending(c); if (rp) return rp; }
     launch_ekf_export_map(c->stream_ekf, c->ekf);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(dst, c->ekf.d_maprec, (size_t)ASLAM_MAP_RECORD_BYTES * c->ekf.max_landmarks,
@@ -1262,6 +1489,7 @@ int aslam_export_map(aslam_ctx* c, void* dst, int dst_is_device) {
 int aslam_export_map_async(aslam_ctx* c, void* d_dst, int buffer) {
     if (!c || !d_dst || buffer < 0 || buffer > 1) return fail(c, ASLAM_E_INVALID, "bad arguments");
     if (!c->ev_export[buffer]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_export[buffer], hipEventDisableTiming));
+    { int rp = finalize_pending(c); if (rp) return rp; }
     launch_ekf_export_map(c->stream_ekf, c->ekf);              // ordered after the EKF steps enqueued so far
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(d_dst, c->ekf.d_maprec, (size_t)ASLAM_MAP_RECORD_BYTES * c->ekf.max_landmarks, hipMemcpyDeviceToDevice, c->stream_ekf));
@@ -1338,6 +1566,7 @@ int aslam_comm_gather_maps(aslam_ctx* c, void* dst, int dst_is_device) {
     if (!c->comm) return fail(c, ASLAM_E_STATE, "aslam_comm_create first");
     Rccl* r = rccl();
     const size_t nb = (size_t)ASLAM_MAP_RECORD_BYTES * c->ekf.max_landmarks;
+    { int rp = finalize_pending(c); if (rp) return rp; }
     launch_ekf_export_map(c->stream_ekf, c->ekf);                  // ordered after the EKF steps enqueued so far
     HIP_TRY(c, hipGetLastError());
     int rc = r->AllGather(c->ekf.d_maprec, c->d_gather, nb, /* ncclInt8 */ 0, c->comm, c->stream_ekf);

@@ -28,6 +28,14 @@ struct MapRecord {                     // 104-byte landmark record gathered acro
     double S[9];
 };
 
+// ---- windowed EKF (ekf_window.hip): runs of frames that fuse the same landmarks --------------------------------------
+constexpr int kWinM = 20;              // landmarks per window frame at most (s = 3 + 3 m <= 63 fits 64 x 64 images)
+constexpr int kWinFrames = 64;         // frames per window at most
+struct WinDesc {                       // one window (kernel argument)
+    int first_slot, K, m, s;           // slots first_slot .. first_slot + K - 1; s = 3 + 3 m
+    int li[kWinM];                     // state offset 3 + 3 index of every landmark, ascending (= pop order, aruco_slam.h:85-88)
+};
+
 struct EkfState {
     int max_landmarks, ld;             // ld = 3 + 3*max_landmarks: leading dimension of sigma (column-major)
     double* d_mu;
@@ -45,6 +53,9 @@ struct EkfState {
     double *d_V, *d_Wt, *d_T;          // 3m x ld each, row k contiguous
     double *d_Sv, *d_Sw, *d_alpha, *d_gamma, *d_G, *d_g;
     MapRecord* d_maprec;
+    double* d_win_log;                 // per window frame: G, W, V images, g, H3, Jacobians (ekf_window.hip)
+    double* d_win_small;               // Lambda, Gamma, Psi, P_K images and psi
+    int* d_win_sidx;                   // per state index: position in S or -1
     int* d_slot_stat;                  // per staged slot, written by k_ekf_plan: detections, augments, fused updates, stationary no-ops
     int max_slots;
 };
@@ -64,5 +75,12 @@ void launch_ekf_gather(hipStream_t st, const EkfState& E);
 void launch_ekf_small(hipStream_t st, const EkfState& E);
 void launch_ekf_T(hipStream_t st, const EkfState& E);
 void launch_ekf_export_map(hipStream_t st, const EkfState& E);
+size_t ekf_win_log_doubles();
+size_t ekf_win_small_doubles();
+// obs / n_markers / enc: the context's per-slot arrays; d_obs_idx: K x kWinM bytes, detection index of the j-th popped observation
+void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs,
+                          const unsigned* n_markers, const double* enc, const unsigned char* d_obs_idx);
+void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd);
+void launch_ekf_win_flush(hipStream_t st, const EkfState& E, const WinDesc& wd);
 
 } // namespace aslam

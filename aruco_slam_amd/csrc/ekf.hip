@@ -13,17 +13,10 @@
 // branch (aruco_slam.cpp:192-198) are excluded; new landmarks are appended first (they pop first).
 #include "common.h"
 #include "ekf.h"
+#include "ekf_dev.h"
 #include <cmath>
 
 namespace aslam {
-
-typedef double v4d __attribute__((vector_size(4 * sizeof(double))));   // accumulator of v_mfma_f64_16x16x4_f64
-
-__device__ __forceinline__ void wrap1(double& a) {      // ArucoSlam::normAngle (aruco_slam.cpp:412-421): wraps once
-    const double PI = 3.14159265358979323846;
-    if (a >= PI) a -= 2.0 * PI;
-    if (a < -PI) a += 2.0 * PI;
-}
 
 __device__ void inv3_pp(const double* A, double* out) {   // 3x3 inverse by partial-pivot LU (Eigen dynamic .inverse())
     double a[3][6];
@@ -722,21 +715,6 @@ constexpr int kFastM = 24;               // fused updates per frame handled by t
 constexpr int kFastN3 = 3 * kFastM;      // 72
 constexpr int MIDT = 576;                // kFastM x kFastM: one thread per 3x3 block of the innovation matrix
 
-__device__ __forceinline__ void inv3_reg(const double* P, double* o) {   // 3x3 inverse (cofactors), row-major
-    const double a = P[0], b = P[1], c = P[2], d = P[3], e = P[4], f = P[5], g = P[6], h = P[7], i = P[8];
-    const double A = e * i - f * h, B = f * g - d * i, C = d * h - e * g;
-    const double id = 1.0 / (a * A + b * B + c * C);
-    o[0] = A * id; o[1] = (c * h - b * i) * id; o[2] = (b * f - c * e) * id;
-    o[3] = B * id; o[4] = (a * i - c * g) * id; o[5] = (c * d - a * f) * id;
-    o[6] = C * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * d) * id;
-}
-__device__ __forceinline__ void mul3(const double* X, const double* Y, double* Z) {   // Z = X * Y (3x3 row-major)
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) Z[i * 3 + j] = X[i * 3] * Y[j] + X[i * 3 + 1] * Y[3 + j] + X[i * 3 + 2] * Y[6 + j];
-}
-
 // <= 128 VGPRs (4 waves per SIMD) so that the workgroup always finds room beside the persistent detection waves of the other stream
 __global__ __launch_bounds__(576, 4) void k_ekf_mid(EkfState E) {
     __shared__ __align__(16) double sCol[2][kFastM][10];   // pivot column blocks (bi, ib); rows padded to 80 B for 128-bit LDS reads
@@ -1350,6 +1328,9 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots) {
     A(dalloc(&E.d_G, n3 * n3));
     A(dalloc(&E.d_g, n3));
     A(dalloc(&E.d_maprec, (size_t)max_landmarks));
+    A(dalloc(&E.d_win_log, ekf_win_log_doubles()));
+    A(dalloc(&E.d_win_small, ekf_win_small_doubles()));
+    A(dalloc(&E.d_win_sidx, ld));
     A(dalloc(&E.d_slot_stat, (size_t)4 * max_slots));
     A(hipMemset(E.d_slot_stat, 0, (size_t)4 * max_slots * sizeof(int)));
     // ArucoSlam::ArucoSlam (aruco_slam.cpp:13-18): mu = 0 (3), sigma = 0 (3x3), empty map
@@ -1369,7 +1350,7 @@ void ekf_free(EkfState& E) {
     hipFree(E.d_mu); hipFree(E.d_sigma); hipFree(E.d_L); hipFree(E.d_id2idx); hipFree(E.d_idx2id); hipFree(E.d_last); hipFree(E.d_lastNext);
     hipFree(E.d_nlast); hipFree(E.d_pop); hipFree(E.d_npop); hipFree(E.d_upd); hipFree(E.d_m); hipFree(E.d_V); hipFree(E.d_Wt);
     hipFree(E.d_T); hipFree(E.d_Sv); hipFree(E.d_Sw); hipFree(E.d_alpha); hipFree(E.d_gamma); hipFree(E.d_G); hipFree(E.d_g);
-    hipFree(E.d_maprec); hipFree(E.d_slot_stat);
+    hipFree(E.d_maprec); hipFree(E.d_slot_stat); hipFree(E.d_win_log); hipFree(E.d_win_small); hipFree(E.d_win_sidx);
     E = EkfState{};
 }
 

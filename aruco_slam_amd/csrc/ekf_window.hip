@@ -1,0 +1,633 @@
+// Windowed EKF: a run of K consecutive frames that fuse the SAME m landmarks (no new landmark, no "stationary" no-op,
+// m <= kWinM) is processed without streaming the N x N covariance once per frame.
+//
+// Split the state into S (robot pose + the m observed landmarks, s = 3 + 3m <= 63) and R (everything else):
+//     Sigma = [ P  Y ]      P = Sigma[S,S]   Y = Sigma[S,R]
+//             [ X  Z ]      X = Sigma[R,S]   Z = Sigma[R,R]
+// Every predict (aruco_slam.cpp:21-74: D = blkdiag(H3, I) on S, process noise on the pose block) and every correction
+// (aruco_slam.cpp:108-207 fused per frame: H = [H_S 0], G = (H_S P' H_S^T + R)^-1, W = P' H_S^T, V = H_S P') touches R only
+// through X and Y, linearly:
+//     P+ = P' - W G V                     Y+ = (D Y) - W G (H_S D Y)                 X+ = (X D^T) - (X D^T H_S^T) G V
+//     Z+ = Z - (X D^T H_S^T) G (H_S D Y)  mu_R+ = mu_R + (X D^T H_S^T) g
+// hence, over the whole window, with s x s accumulators Lambda, Gamma, Psi and a vector psi
+//     Y_K = Lambda Y_0      X_K = X_0 Gamma      Z_K = Z_0 - X_0 Psi Y_0      mu_R,K = mu_R,0 + X_0 psi
+//     Lambda+ = D Lambda - W G B       Gamma+ = Gamma D^T - A G V       Psi+ = Psi + A G B      psi+ = psi + A g
+//     with  B = H_S D Lambda  (3m x s),   A = Gamma D^T H_S^T  (s x 3m).
+// This is the reference's arithmetic regrouped (no symmetry of Sigma is assumed, nothing is approximated): the same identity
+// that fuses one frame's M corrections (ekf.hip) applied across frames.  Three kernels per window:
+//   k_ekf_win_chain   one workgroup runs the K frames on P and mu_S held in LDS (predict, records, innovation matrix,
+//                     block Gauss-Jordan, P update on the f64 matrix cores) and logs G, W, V, g, H3 and the Jacobians of every
+//                     frame; further workgroups copy X_0 (columns S of Sigma) and Y_0 (rows S) aside meanwhile;
+//   k_ekf_win_scan    4 x 4 workgroups replay the log: workgroup (i, j) carries 16 columns of Lambda, 16 rows of Gamma and
+//                     the 16 x 16 block of Psi they determine (columns of Lambda and rows of Gamma evolve independently);
+//   k_ekf_win_flush   one workgroup per 64 x 64 tile of Sigma: Z tile -= X_0 (Psi Y_0), rows / columns of S replaced by
+//                     Lambda Y_0 / X_0 Gamma / P_K, mu_R += X_0 psi - the ONE pass over Sigma per window.
+#include "common.h"
+#include "ekf.h"
+#include "ekf_dev.h"
+#include <cmath>
+
+namespace aslam {
+
+constexpr int WS = 66;                        // row stride (doubles) of a 64 x 64 image: conflict-free MFMA A-operand reads from LDS
+constexpr int WIMG = 64 * WS;                 // doubles per image
+constexpr int WLOG_G = 0, WLOG_W = WIMG, WLOG_V = 2 * WIMG, WLOG_g = 3 * WIMG, WLOG_H3 = WLOG_g + 64, WLOG_HREC = WLOG_H3 + 16;
+constexpr int WLOG_STRIDE = WLOG_HREC + kWinM * 18;     // doubles per logged frame
+constexpr int WSM_LAM = 0, WSM_GAM = WIMG, WSM_PSI = 2 * WIMG, WSM_P = 3 * WIMG, WSM_psi = 4 * WIMG;    // layout of d_win_small
+constexpr int WCT = 512;                      // threads of the chain workgroup
+
+size_t ekf_win_log_doubles() { return (size_t)WLOG_STRIDE * kWinFrames; }
+size_t ekf_win_small_doubles() { return (size_t)4 * WIMG + 64; }
+
+__device__ __forceinline__ int win_state_index(const WinDesc& wd, int p) {      // state offset of position p of S
+    return p < 3 ? p : wd.li[(p - 3) / 3] + (p - 3) % 3;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp, WinDesc wd, const ObsRaw* __restrict__ obs,
+                                                      const unsigned* __restrict__ n_markers, const double* __restrict__ enc,
+                                                      const unsigned char* __restrict__ obs_idx) {
+    __shared__ __align__(16) double sP[WIMG];
+    __shared__ __align__(16) double sW[WIMG];
+    __shared__ __align__(16) double sV[WIMG];          // V, later J = G V
+    __shared__ __align__(16) double sG[WIMG];
+    __shared__ double sMu[64], sg[64], sZe[64], sNu[64];
+    __shared__ double sHr[kWinM][9], sHl[kWinM][9], sRd[kWinM][3];
+    __shared__ double sH3[9], sQ[9], sPose[5];
+    __shared__ __align__(16) double sCol[2][kWinM][10];
+    __shared__ __align__(16) double sRow[2][kWinM][10];
+    __shared__ __align__(16) double sPinv[2][10];
+    __shared__ double sPart[kWinM][kWinM][3];
+    __shared__ int sS[64];
+    const int tid = threadIdx.x;
+    const int m = wd.m, s = wd.s, n3 = 3 * m;
+    const int ld = E.ld;
+
+    if (blockIdx.x > 0) {
+        // ---- X_0^T (row p = column S_p of Sigma) -> d_Wt, Y_0 (row p = row S_p of Sigma) -> d_V, S-position table ----
+        const int N = 3 + 3 * (*E.d_L);
+        for (int t = (blockIdx.x - 1) * WCT + tid; t < N; t += (gridDim.x - 1) * WCT) {
+            int pos = -1;
+            if (t < 3) pos = t;
+            else {
+                const int base = (t - 3) / 3 * 3 + 3;
+                for (int a = 0; a < m; a++) if (wd.li[a] == base) pos = 3 + 3 * a + (t - base);
+            }
+            E.d_win_sidx[t] = pos;
+            for (int p = 0; p < s; p++) {
+                const int Sp = win_state_index(wd, p);
+                E.d_Wt[(size_t)p * ld + t] = E.d_sigma[(size_t)Sp * ld + t];
+                E.d_V[(size_t)p * ld + t] = E.d_sigma[(size_t)t * ld + Sp];
+            }
+        }
+        return;
+    }
+
+    // ---- workgroup 0: P = Sigma[S,S] and mu_S into LDS (zero padded to 64) ----
+    if (tid < 64) { sS[tid] = tid < s ? win_state_index(wd, tid) : 0; sMu[tid] = 0.0; sg[tid] = 0.0; }
+    for (int e = tid; e < WIMG; e += WCT) { sP[e] = 0.0; sW[e] = 0.0; sV[e] = 0.0; sG[e] = 0.0; }
+    __syncthreads();
+    if (tid < s) sMu[tid] = E.d_mu[sS[tid]];
+    for (int e = tid; e < s * s; e += WCT) {
+        const int q = e / s, p = e - q * s;                        // column q, row p: consecutive threads walk down a column
+        sP[p * WS + q] = E.d_sigma[(size_t)sS[q] * ld + sS[p]];
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int bj = tid % m, bi = tid / m;                          // Gauss-Jordan block owned by this thread
+    const bool act = bi < m;
+    // prefetch of the first frame's inputs
+    ObsRaw myObs{};
+    if (tid < m) myObs = obs[(size_t)wd.first_slot * kMarkerMax + obs_idx[tid]];
+    double e_wl = 0, e_wr = 0, e_dt = 0;
+    if (tid == 0) { const double* e = enc + (size_t)3 * wd.first_slot; e_wl = e[0]; e_wr = e[1]; e_dt = e[2]; }
+    __syncthreads();
+
+    for (int k = 0; k < wd.K; k++) {
+        const int slot = wd.first_slot + k;
+        double* log = E.d_win_log + (size_t)k * WLOG_STRIDE;
+        // ---- 1. predict (aruco_slam.cpp:35-73): pose, H3, Qk ----
+        if (tid == 0) {
+            const double delta_sl = sp.kl * (e_dt * e_wl), delta_sr = sp.kr * (e_dt * e_wr);
+            const double delta_theta = (delta_sr - delta_sl) / (2 * sp.b);
+            const double delta_s = 0.5 * (delta_sr + delta_sl);
+            const double m0 = sMu[0], m1 = sMu[1], m2 = sMu[2];
+            double c, sn;
+            sincos(m2 + 0.5 * delta_theta, &sn, &c);
+            double th = m2 + delta_theta;
+            wrap1(th);
+            sMu[0] = m0 + delta_s * c; sMu[1] = m1 + delta_s * sn; sMu[2] = th;
+            sH3[0] = 1.0; sH3[1] = 0.0; sH3[2] = -delta_s * sn;
+            sH3[3] = 0.0; sH3[4] = 1.0; sH3[5] = delta_s * c;
+            sH3[6] = 0.0; sH3[7] = 0.0; sH3[8] = 1.0;
+            const double f = 0.5 * sp.kl * e_dt;                    // kl for BOTH wheels (quirk Q7)
+            const double wkh[6] = {f * c, f * c, f * sn, f * sn, f * (1 / sp.b), f * (-1 / sp.b)};
+            const double su0 = sp.Q_k * fabs(e_wl), su1 = sp.Q_k * fabs(e_wr);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) sQ[i * 3 + j] = wkh[i * 2] * su0 * wkh[j * 2] + wkh[i * 2 + 1] * su1 * wkh[j * 2 + 1];
+            sPose[0] = sMu[0]; sPose[1] = sMu[1]; sPose[2] = th;
+            sincos(th, &sPose[3], &sPose[4]);
+            for (int i = 0; i < 9; i++) log[WLOG_H3 + i] = sH3[i];
+        }
+        __syncthreads();
+        if (tid < s) {                                              // rows 0..2 <- H3 * rows 0..2 (every column)
+            const double a = sP[tid], b = sP[WS + tid], c = sP[2 * WS + tid];
+            sP[tid] = sH3[0] * a + sH3[1] * b + sH3[2] * c;
+            sP[WS + tid] = sH3[3] * a + sH3[4] * b + sH3[5] * c;
+            sP[2 * WS + tid] = sH3[6] * a + sH3[7] * b + sH3[8] * c;
+        }
+        __syncthreads();
+        if (tid < s) {                                              // columns 0..2 <- columns 0..2 * H3^T (every row), + Qk on the pose block
+            double* row = sP + tid * WS;
+            const double a = row[0], b = row[1], c = row[2];
+            double v0 = a * sH3[0] + b * sH3[1] + c * sH3[2], v1 = a * sH3[3] + b * sH3[4] + c * sH3[5], v2 = a * sH3[6] + b * sH3[7] + c * sH3[8];
+            if (tid < 3) { v0 += sQ[tid * 3]; v1 += sQ[tid * 3 + 1]; v2 += sQ[tid * 3 + 2]; }
+            row[0] = v0; row[1] = v1; row[2] = v2;
+        }
+        // ---- 2. records of the m corrections (aruco_slam.cpp:119-143), linearised at the frozen mean ----
+        if (tid < m) {
+            const int a = tid;
+            const double mu0x = sPose[0], mu0y = sPose[1], mu0t = sPose[2], sintheta = sPose[3], costheta = sPose[4];
+            const double mx = sMu[3 + 3 * a], my = sMu[4 + 3 * a], mth = sMu[5 + 3 * a];
+            double gdx = mx - mu0x, gdy = my - mu0y, gdth = mth - mu0t;
+            wrap1(gdth);
+            const double zh0 = gdx * costheta + gdy * sintheta, zh1 = -gdx * sintheta + gdy * costheta;
+            double z2 = myObs.th - gdth;
+            wrap1(z2);
+            sZe[3 * a] = myObs.x - zh0; sZe[3 * a + 1] = myObs.y - zh1; sZe[3 * a + 2] = z2;
+            sNu[3 * a] = sZe[3 * a]; sNu[3 * a + 1] = sZe[3 * a + 1]; sNu[3 * a + 2] = sZe[3 * a + 2];
+            const double G[18] = {-costheta, -sintheta, -gdx * sintheta + gdy * costheta, costheta, sintheta, 0,
+                                  sintheta, -costheta, -gdx * costheta - gdy * sintheta, -sintheta, costheta, 0,
+                                  0, 0, -1, 0, 0, 1};
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) { sHr[a][r * 3 + c] = G[r * 6 + c]; sHl[a][r * 3 + c] = G[r * 6 + 3 + c]; }
+            sRd[a][0] = myObs.r[0]; sRd[a][1] = myObs.r[1]; sRd[a][2] = myObs.r[2];
+            for (int q = 0; q < 18; q++) log[WLOG_HREC + a * 18 + q] = G[q];
+            if (k == wd.K - 1) {                                    // what the frame leaves behind for whatever follows the window
+                PopRec pr;
+                pr.id = myObs.id; pr.index = (wd.li[a] - 3) / 3; pr.action = 1; pr.pad = 0;
+                pr.z[0] = myObs.x; pr.z[1] = myObs.y; pr.z[2] = myObs.th;
+                pr.r[0] = myObs.r[0]; pr.r[1] = myObs.r[1]; pr.r[2] = myObs.r[2];
+                E.d_pop[a] = pr;
+                LastObs lo;
+                lo.id = myObs.id; lo.pad = 0; lo.z[0] = myObs.x; lo.z[1] = myObs.y; lo.z[2] = myObs.th;   // update branch (aruco_slam.cpp:202)
+                E.d_last[a] = lo;
+            }
+        }
+        if (tid == 0 && slot < E.max_slots) {
+            int* st = E.d_slot_stat + 4 * slot;
+            st[0] = (int)min(n_markers[slot], (unsigned)kMarkerMax); st[1] = 0; st[2] = m; st[3] = 0;
+        }
+        __syncthreads();
+        // the next frame's inputs are fetched while this one is solved
+        if (k + 1 < wd.K) {
+            if (tid < m) myObs = obs[(size_t)(slot + 1) * kMarkerMax + obs_idx[(size_t)(k + 1) * kWinM + tid]];
+            if (tid == 0) { const double* e = enc + (size_t)3 * (slot + 1); e_wl = e[0]; e_wr = e[1]; e_dt = e[2]; }
+        }
+        // ---- 3. W = P' H^T (s x 3m), V = H P' (3m x s); 3x3 block (i, a): block row / column i of S, correction a ----
+        if (tid < (m + 1) * m) {
+            const int i = tid / m, a = tid - i * m;
+            double Pa[9], Pb[9], Pc[9], Pd[9];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    Pa[r * 3 + c] = sP[(3 * i + r) * WS + c];                    // P[i, 0]
+                    Pb[r * 3 + c] = sP[(3 * i + r) * WS + 3 + 3 * a + c];        // P[i, 1 + a]
+                    Pc[r * 3 + c] = sP[r * WS + 3 * i + c];                      // P[0, i]
+                    Pd[r * 3 + c] = sP[(3 + 3 * a + r) * WS + 3 * i + c];        // P[1 + a, i]
+                }
+            const double* Hr = sHr[a];
+            const double* Hl = sHl[a];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    // (P[i,0] Hr^T + P[i,1+a] Hl^T)[r][c]
+                    sW[(3 * i + r) * WS + 3 * a + c] = (Pa[r * 3] * Hr[c * 3] + Pa[r * 3 + 1] * Hr[c * 3 + 1] + Pa[r * 3 + 2] * Hr[c * 3 + 2]) +
+                                                       (Pb[r * 3] * Hl[c * 3] + Pb[r * 3 + 1] * Hl[c * 3 + 1] + Pb[r * 3 + 2] * Hl[c * 3 + 2]);
+                    // (Hr P[0,i] + Hl P[1+a,i])[r][c]
+                    sV[(3 * a + r) * WS + 3 * i + c] = (Hr[r * 3] * Pc[c] + Hr[r * 3 + 1] * Pc[3 + c] + Hr[r * 3 + 2] * Pc[6 + c]) +
+                                                       (Hl[r * 3] * Pd[c] + Hl[r * 3 + 1] * Pd[3 + c] + Hl[r * 3 + 2] * Pd[6 + c]);
+                }
+        }
+        __syncthreads();
+        // ---- 4. innovation matrix A = H W + R (aruco_slam.cpp:146), 3x3 block (bi, bj) in registers; block Gauss-Jordan ----
+        double A[9];
+        if (act) {
+            double W0[9], W1[9];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) { W0[r * 3 + c] = sW[r * WS + 3 * bj + c]; W1[r * 3 + c] = sW[(3 + 3 * bi + r) * WS + 3 * bj + c]; }
+            const double* Hr = sHr[bi];
+            const double* Hl = sHl[bi];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    A[r * 3 + c] = (Hr[r * 3] * W0[c] + Hr[r * 3 + 1] * W0[3 + c] + Hr[r * 3 + 2] * W0[6 + c]) +
+                                   (Hl[r * 3] * W1[c] + Hl[r * 3 + 1] * W1[3 + c] + Hl[r * 3 + 2] * W1[6 + c]);
+            if (bi == bj) { A[0] += sRd[bi][0]; A[4] += sRd[bi][1]; A[8] += sRd[bi][2]; }
+            if (bj == 0) { for (int q = 0; q < 9; q++) sCol[0][bi][q] = A[q]; }
+            if (bi == 0) { for (int q = 0; q < 9; q++) sRow[0][bj][q] = A[q]; }
+            if (bi == 0 && bj == 0) {
+                double Pn[9];
+                inv3_reg(A, Pn);
+                for (int q = 0; q < 9; q++) sPinv[0][q] = Pn[q];
+            }
+        }
+        __syncthreads();
+        // pivot block ib IS S_ib = H_ib Sigma_{ib-1} H_ib^T + R_ib; block multiplier F S^-1 of a later row block IS H_bi K_ib
+        // (the reference's own recursion, see k_ekf_mid); one barrier per step
+        for (int ib = 0; ib < m; ib++) {
+            const int cb = ib & 1;
+            if (act) {
+                double Pi[9], Y[9];
+#pragma unroll
+                for (int q = 0; q < 9; q++) Pi[q] = sPinv[cb][q];
+                if (bj == ib) {
+#pragma unroll
+                    for (int q = 0; q < 9; q++) Y[q] = Pi[q];
+                } else {
+                    double R[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) R[q] = sRow[cb][bj][q];
+                    mul3(Pi, R, Y);
+                }
+                if (bi == ib) {
+#pragma unroll
+                    for (int q = 0; q < 9; q++) A[q] = Y[q];
+                } else {
+                    double F[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) F[q] = sCol[cb][bi][q];
+                    if (bj == ib) {
+#pragma unroll
+                        for (int q = 0; q < 9; q++) A[q] = 0.0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++)
+                            A[i * 3 + j] = fma(-F[i * 3 + 2], Y[6 + j], fma(-F[i * 3 + 1], Y[3 + j], fma(-F[i * 3], Y[j], A[i * 3 + j])));
+                    if (bj == ib && bi > ib) {
+                        const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
+#pragma unroll
+                        for (int a = 0; a < 3; a++) sNu[3 * bi + a] -= A[a * 3] * z0 + A[a * 3 + 1] * z1 + A[a * 3 + 2] * z2;   // nu += (H K) ze, H K = -A
+                    }
+                }
+                if (bi == ib + 1) { for (int q = 0; q < 9; q++) sRow[cb ^ 1][bj][q] = A[q]; }
+                if (bj == ib + 1) { for (int q = 0; q < 9; q++) sCol[cb ^ 1][bi][q] = A[q]; }
+                if (bi == ib + 1 && bj == ib + 1) {
+                    double Pn[9];
+                    inv3_reg(A, Pn);
+#pragma unroll
+                    for (int q = 0; q < 9; q++) sPinv[cb ^ 1][q] = Pn[q];
+                }
+            }
+            __syncthreads();
+        }
+        if (act) {                                                  // G = A^-1 into LDS, partial sums of g = G nu
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 3; b++) sG[(3 * bi + a) * WS + 3 * bj + b] = A[a * 3 + b];
+            const double n0 = sNu[3 * bj], n1 = sNu[3 * bj + 1], n2 = sNu[3 * bj + 2];
+#pragma unroll
+            for (int a = 0; a < 3; a++) sPart[bi][bj][a] = A[a * 3] * n0 + A[a * 3 + 1] * n1 + A[a * 3 + 2] * n2;
+        }
+        __syncthreads();
+        if (tid < n3) {
+            const int i = tid / 3, a = tid - 3 * i;
+            double acc = 0;
+            for (int j = 0; j < m; j++) acc += sPart[i][j][a];
+            sg[tid] = acc;
+        }
+        // ---- 5. log G, W, V (stores only: they drain while the matrix cores work) ----
+        for (int e = tid; e < WIMG; e += WCT) { log[WLOG_G + e] = sG[e]; log[WLOG_W + e] = sW[e]; log[WLOG_V + e] = sV[e]; }
+        // ---- 6. J = G V on the f64 matrix cores: wave w owns tile row w >> 1 and two column tiles ----
+        const int tr = wave >> 1, tc0 = 2 * (wave & 1);
+        {
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            for (int p0 = 0; p0 < 64; p0 += 4) {
+                const double a = sG[(16 * tr + li) * WS + p0 + lk];
+                const double b0 = sV[(p0 + lk) * WS + 16 * tc0 + li], b1 = sV[(p0 + lk) * WS + 16 * tc0 + 16 + li];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+            }
+            __syncthreads();                                        // every wave has read V (and sg is complete)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                sV[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li] = acc0[reg];
+                sV[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + 16 + li] = acc1[reg];
+            }
+        }
+        if (tid < 64) log[WLOG_g + tid] = sg[tid];
+        __syncthreads();
+        // ---- 7. P <- P' - W J (aruco_slam.cpp:204 regrouped), mu_S += W g (:203) ----
+        {
+            v4d acc0, acc1;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                acc0[reg] = sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li];
+                acc1[reg] = sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + 16 + li];
+            }
+            for (int p0 = 0; p0 < 64; p0 += 4) {
+                const double a = -sW[(16 * tr + li) * WS + p0 + lk];
+                const double b0 = sV[(p0 + lk) * WS + 16 * tc0 + li], b1 = sV[(p0 + lk) * WS + 16 * tc0 + 16 + li];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li] = acc0[reg];
+                sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + 16 + li] = acc1[reg];
+            }
+        }
+        if (tid < s) {
+            double acc = 0;
+            for (int c = 0; c < n3; c++) acc += sW[tid * WS + c] * sg[c];
+            sMu[tid] += acc;
+        }
+        __syncthreads();
+        // V's image (now J) is rebuilt next frame; its padding must be zero again
+        for (int e = tid; e < WIMG; e += WCT) sV[e] = 0.0;
+        __syncthreads();
+    }
+    // ---- the window's result on S: P_K for the flush, mu_S in place; bookkeeping of the last frame ----
+    double* small = E.d_win_small;
+    for (int e = tid; e < WIMG; e += WCT) small[WSM_P + e] = sP[e];
+    if (tid < s) E.d_mu[sS[tid]] = sMu[tid];
+    if (tid == 0) { *E.d_nlast = m; *E.d_npop = m; *E.d_m = m; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Replay of the log: workgroup (x = j, y = i) carries Lambda[:, 16j .. 16j+15], Gamma[16i .. 16i+15, :], Psi block (i, j).
+__global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
+    __shared__ __align__(16) double sG[WIMG];
+    __shared__ __align__(16) double sW[WIMG];
+    __shared__ __align__(16) double sV[WIMG];
+    __shared__ double sLam[64][17];            // Lambda columns (s x 16)
+    __shared__ double sGam[16][WS];            // Gamma rows (16 x s)
+    __shared__ double sB[64][17], sGB[64][17]; // B = H D Lambda (3m x 16), G B
+    __shared__ double sA[16][WS], sAG[16][WS]; // A = Gamma D^T H^T (16 x 3m), A G
+    __shared__ double sPsi[16][17], spsi[16], sgv[64], sH3[9];
+    __shared__ double sHrec[kWinM][18];
+    double (*sPsiPart)[16][16] = reinterpret_cast<double (*)[16][16]>(&sAG[0][0]);   // A G is dead once Gamma has been updated
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int bj = blockIdx.x, bi = blockIdx.y;
+    const int m = wd.m, n3 = 3 * m;
+    // Lambda = Gamma = I, Psi = 0, psi = 0
+    for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; sLam[r][c] = (r == 16 * bj + c && r < wd.s) ? 1.0 : 0.0; }
+    for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; sGam[r][c] = (c == 16 * bi + r && c < wd.s) ? 1.0 : 0.0; }
+    for (int e = tid; e < 16 * 16; e += 256) sPsi[e >> 4][e & 15] = 0.0;
+    if (tid < 16) spsi[tid] = 0.0;
+    for (int e = tid; e < 64 * 17; e += 256) { (&sB[0][0])[e] = 0.0; (&sGB[0][0])[e] = 0.0; }
+    for (int e = tid; e < 16 * WS; e += 256) { (&sA[0][0])[e] = 0.0; (&sAG[0][0])[e] = 0.0; }
+    __syncthreads();
+    for (int k = 0; k < wd.K; k++) {
+        const double* log = E.d_win_log + (size_t)k * WLOG_STRIDE;
+        for (int e = tid; e < WIMG; e += 256) { sG[e] = log[WLOG_G + e]; sW[e] = log[WLOG_W + e]; sV[e] = log[WLOG_V + e]; }
+        if (tid < 64) sgv[tid] = log[WLOG_g + tid];
+        if (tid < 9) sH3[tid] = log[WLOG_H3 + tid];
+        for (int e = tid; e < m * 18; e += 256) (&sHrec[0][0])[e] = log[WLOG_HREC + e];
+        __syncthreads();
+        // D Lambda (rows 0..2) and Gamma D^T (columns 0..2)
+        if (tid < 16) {
+            const double a = sLam[0][tid], b = sLam[1][tid], c = sLam[2][tid];
+            sLam[0][tid] = sH3[0] * a + sH3[1] * b + sH3[2] * c;
+            sLam[1][tid] = sH3[3] * a + sH3[4] * b + sH3[5] * c;
+            sLam[2][tid] = sH3[6] * a + sH3[7] * b + sH3[8] * c;
+        } else if (tid < 32) {
+            const int r = tid - 16;
+            const double a = sGam[r][0], b = sGam[r][1], c = sGam[r][2];
+            sGam[r][0] = a * sH3[0] + b * sH3[1] + c * sH3[2];
+            sGam[r][1] = a * sH3[3] + b * sH3[4] + c * sH3[5];
+            sGam[r][2] = a * sH3[6] + b * sH3[7] + c * sH3[8];
+        }
+        __syncthreads();
+        // B[3a+r][c] = Hr_a[r,:] Lambda'[0:3, c] + Hl_a[r,:] Lambda'[3+3a .. , c];   A[r'][3a+r] = Gamma'[r', 0:3] Hr_a[r,:]^T + Gamma'[r', 3+3a ..] Hl_a[r,:]^T
+        for (int e = tid; e < n3 * 16; e += 256) {
+            const int row = e >> 4, c = e & 15, a = row / 3, r = row - 3 * a;
+            const double* h = &sHrec[a][r * 6];
+            sB[row][c] = (h[0] * sLam[0][c] + h[1] * sLam[1][c] + h[2] * sLam[2][c]) +
+                         (h[3] * sLam[3 + 3 * a][c] + h[4] * sLam[4 + 3 * a][c] + h[5] * sLam[5 + 3 * a][c]);
+        }
+        for (int e = tid; e < 16 * n3; e += 256) {
+            const int rp = e / n3, col = e - rp * n3, a = col / 3, r = col - 3 * a;
+            const double* h = &sHrec[a][r * 6];
+            const double* g = sGam[rp];
+            sA[rp][col] = (g[0] * h[0] + g[1] * h[1] + g[2] * h[2]) + (g[3 + 3 * a] * h[3] + g[4 + 3 * a] * h[4] + g[5 + 3 * a] * h[5]);
+        }
+        __syncthreads();
+        // GB = G B (wave w: tile row w), AG = A G (wave w: tile column w)
+        {
+            v4d accB = {0.0, 0.0, 0.0, 0.0}, accA = {0.0, 0.0, 0.0, 0.0};
+            for (int p0 = 0; p0 < 64; p0 += 4) {
+                const double a1 = sG[(16 * wave + li) * WS + p0 + lk], b1 = sB[p0 + lk][li];
+                accB = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accB, 0, 0, 0);
+                const double a2 = sA[li][p0 + lk], b2 = sG[(p0 + lk) * WS + 16 * wave + li];
+                accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accA, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) { sGB[16 * wave + lk + 4 * reg][li] = accB[reg]; sAG[lk + 4 * reg][16 * wave + li] = accA[reg]; }
+        }
+        __syncthreads();
+        // Lambda -= W GB (wave w: tile row w), Gamma -= AG V (wave w: tile column w), Psi += A GB (depth split over the waves)
+        {
+            v4d accL, accG, accP = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) { accL[reg] = sLam[16 * wave + lk + 4 * reg][li]; accG[reg] = sGam[lk + 4 * reg][16 * wave + li]; }
+            for (int p0 = 0; p0 < 64; p0 += 4) {
+                const double a1 = -sW[(16 * wave + li) * WS + p0 + lk], b1 = sGB[p0 + lk][li];
+                accL = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accL, 0, 0, 0);
+                const double a2 = -sAG[li][p0 + lk], b2 = sV[(p0 + lk) * WS + 16 * wave + li];
+                accG = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accG, 0, 0, 0);
+            }
+            for (int p0 = 16 * wave; p0 < 16 * wave + 16; p0 += 4) {
+                const double a3 = sA[li][p0 + lk], b3 = sGB[p0 + lk][li];
+                accP = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, accP, 0, 0, 0);
+            }
+            __syncthreads();                                        // every wave has read the old Lambda / Gamma rows it needs (A, B were formed before)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                sLam[16 * wave + lk + 4 * reg][li] = accL[reg];
+                sGam[lk + 4 * reg][16 * wave + li] = accG[reg];
+                sPsiPart[wave][lk + 4 * reg][li] = accP[reg];
+            }
+        }
+        if (tid < 16) {                                             // psi += A g
+            double acc = 0;
+            for (int c = 0; c < n3; c++) acc += sA[tid][c] * sgv[c];
+            spsi[tid] += acc;
+        }
+        __syncthreads();
+        { const int r = tid >> 4, c = tid & 15; sPsi[r][c] += (sPsiPart[0][r][c] + sPsiPart[1][r][c]) + (sPsiPart[2][r][c] + sPsiPart[3][r][c]); }
+        __syncthreads();
+    }
+    double* small = E.d_win_small;
+    if (bi == 0) for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; small[WSM_LAM + r * WS + 16 * bj + c] = sLam[r][c]; }
+    if (bj == 0) for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; small[WSM_GAM + (16 * bi + r) * WS + c] = sGam[r][c]; }
+    { const int r = tid >> 4, c = tid & 15; small[WSM_PSI + (16 * bi + r) * WS + 16 * bj + c] = sPsi[r][c]; }
+    if (bj == 0 && tid < 16) small[WSM_psi + 16 * bi + tid] = spsi[tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The one pass over Sigma per window.  Tile (r0, c0), 64 x 64: T = Psi Y_0tile, Sigma_tile -= X_0tile T (formed transposed so
+// that the read-modify-write of the column-major Sigma is coalesced, as k_ekf_apply does), then the rows / columns that belong to
+// S are replaced: row S_p <- (Lambda Y_0)[p, :], column S_q <- (X_0 Gamma)[:, q], (S_p, S_q) <- P_K[p][q]; mu_R += X_0 psi.
+__global__ __launch_bounds__(256) void k_ekf_win_flush(EkfState E, WinDesc wd) {
+    __shared__ __align__(16) double sM[WIMG];          // Psi, later Lambda / Gamma
+    __shared__ double sY[64][64];                      // Y_0 tile: [p][column]
+    __shared__ double sX[64][64];                      // X_0^T tile: [p][row]
+    __shared__ double sT[64][64];                      // product tile
+    __shared__ int sRowPos[64], sColPos[64], sAnyRow, sAnyCol;
+    const int ld = E.ld;
+    const int N = 3 + 3 * (*E.d_L);
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    if (r0 >= N || c0 >= N) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
+    const int s = wd.s;
+    const double* small = E.d_win_small;
+    double sig[4][4];
+#pragma unroll
+    for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
+            sig[ri][reg] = (r < N && c < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
+        }
+    for (int e = tid; e < WIMG; e += 256) sM[e] = small[WSM_PSI + e];
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int p = e >> 6, x = e & 63;
+        sY[p][x] = (p < s && c0 + x < N) ? E.d_V[(size_t)p * ld + c0 + x] : 0.0;
+        sX[p][x] = (p < s && r0 + x < N) ? E.d_Wt[(size_t)p * ld + r0 + x] : 0.0;
+    }
+    if (tid < 64) {
+        sRowPos[tid] = r0 + tid < N ? E.d_win_sidx[r0 + tid] : -1;
+        sColPos[tid] = c0 + tid < N ? E.d_win_sidx[c0 + tid] : -1;
+    }
+    if (tid == 0) { sAnyRow = 0; sAnyCol = 0; }
+    __syncthreads();
+    if (tid < 64) { if (sRowPos[tid] >= 0) sAnyRow = 1; if (sColPos[tid] >= 0) sAnyCol = 1; }
+    // T = Psi Y_0tile: wave w owns columns 16w .. 16w+15 and all four 16-row tiles
+    {
+        v4d acc[4];
+#pragma unroll
+        for (int qi = 0; qi < 4; qi++) acc[qi] = v4d{0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < 64; p0 += 4) {
+            const double b = sY[p0 + lk][16 * wave + li];
+#pragma unroll
+            for (int qi = 0; qi < 4; qi++) acc[qi] = __builtin_amdgcn_mfma_f64_16x16x4f64(sM[(16 * qi + li) * WS + p0 + lk], b, acc[qi], 0, 0, 0);
+        }
+#pragma unroll
+        for (int qi = 0; qi < 4; qi++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) sT[16 * qi + lk + 4 * reg][16 * wave + li] = acc[qi][reg];
+    }
+    __syncthreads();
+    const bool anyRow = sAnyRow != 0, anyCol = sAnyCol != 0;       // uniform
+    // Sigma tile (transposed product): D'[c][r] = sum_p T[p][c] X_0^T[p][r]
+    {
+        v4d acc[4];
+#pragma unroll
+        for (int ri = 0; ri < 4; ri++) acc[ri] = v4d{0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < 64; p0 += 4) {
+            const double a = sT[p0 + lk][16 * wave + li];
+#pragma unroll
+            for (int ri = 0; ri < 4; ri++) acc[ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[p0 + lk][16 * ri + li], acc[ri], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) sig[ri][reg] -= acc[ri][reg];
+    }
+    if (anyRow) {
+        // rows of S: (Lambda Y_0)[p][c]
+        __syncthreads();
+        for (int e = tid; e < WIMG; e += 256) sM[e] = small[WSM_LAM + e];
+        __syncthreads();
+        v4d acc[4];
+#pragma unroll
+        for (int qi = 0; qi < 4; qi++) acc[qi] = v4d{0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < 64; p0 += 4) {
+            const double b = sY[p0 + lk][16 * wave + li];
+#pragma unroll
+            for (int qi = 0; qi < 4; qi++) acc[qi] = __builtin_amdgcn_mfma_f64_16x16x4f64(sM[(16 * qi + li) * WS + p0 + lk], b, acc[qi], 0, 0, 0);
+        }
+#pragma unroll
+        for (int qi = 0; qi < 4; qi++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) sT[16 * qi + lk + 4 * reg][16 * wave + li] = acc[qi][reg];     // sT[p][column]
+        __syncthreads();
+#pragma unroll
+        for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int cl = 16 * wave + lk + 4 * reg, rl = 16 * ri + li;
+                const int p = sRowPos[rl];
+                if (p >= 0) sig[ri][reg] = sT[p][cl];
+            }
+    }
+    if (anyCol) {
+        // columns of S: (X_0 Gamma)[r][q] = sum_p X_0^T[p][r] Gamma[p][q]; formed as D[q][r] with A[i = q][k = p] = Gamma[p][q]
+        __syncthreads();
+        for (int e = tid; e < WIMG; e += 256) sM[e] = small[WSM_GAM + e];
+        __syncthreads();
+        v4d acc[4];
+#pragma unroll
+        for (int qi = 0; qi < 4; qi++) acc[qi] = v4d{0.0, 0.0, 0.0, 0.0};
+        for (int p0 = 0; p0 < 64; p0 += 4) {
+            const double b = sX[p0 + lk][16 * wave + li];                                                   // B[k = p][j = r]
+#pragma unroll
+            for (int qi = 0; qi < 4; qi++) acc[qi] = __builtin_amdgcn_mfma_f64_16x16x4f64(sM[(p0 + lk) * WS + 16 * qi + li], b, acc[qi], 0, 0, 0);
+        }
+#pragma unroll
+        for (int qi = 0; qi < 4; qi++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) sT[16 * qi + lk + 4 * reg][16 * wave + li] = acc[qi][reg];     // sT[q][row]
+        __syncthreads();
+#pragma unroll
+        for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int cl = 16 * wave + lk + 4 * reg, rl = 16 * ri + li;
+                const int q = sColPos[cl];
+                if (q >= 0) {
+                    const int p = sRowPos[rl];
+                    sig[ri][reg] = p >= 0 ? small[WSM_P + p * WS + q] : sT[q][rl];
+                }
+            }
+    }
+#pragma unroll
+    for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
+            if (r < N && c < N) E.d_sigma[(size_t)c * ld + r] = sig[ri][reg];
+        }
+    if (blockIdx.y == 0 && tid < 64 && r0 + tid < N && sRowPos[tid] < 0) {
+        double acc = 0;
+        for (int p = 0; p < s; p++) acc += sX[p][tid] * small[WSM_psi + p];
+        E.d_mu[r0 + tid] += acc;                                   // mu_R += X_0 psi
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs,
+                          const unsigned* n_markers, const double* enc, const unsigned char* d_obs_idx) {
+    const int ngather = (E.ld + WCT - 1) / WCT;
+    hipLaunchKernelGGL(k_ekf_win_chain, dim3(1 + ngather), dim3(WCT), 0, st, E, sp, wd, obs, n_markers, enc, d_obs_idx);
+}
+void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd) {
+    hipLaunchKernelGGL(k_ekf_win_scan, dim3(4, 4), dim3(256), 0, st, E, wd);
+}
+void launch_ekf_win_flush(hipStream_t st, const EkfState& E, const WinDesc& wd) {
+    const int t = (E.ld + 63) / 64;
+    hipLaunchKernelGGL(k_ekf_win_flush, dim3(t, t), dim3(256), 0, st, E, wd);
+}
+
+} // namespace aslam

@@ -157,7 +157,7 @@ def scene_setup(np, capi, synth, cfg_name, rank, local_rank, args, with_ekf, dow
     host = None
     if download:
         host = np.stack([ctx.synth_render(i, cfg.rows, cfg.cols, world.K, frames[i].ids, frames[i].poses, noise_amp=2, seed=seeds[i])
-                         for i in range(download)])
+                         for i in range(min(download, lap))])
     ctx.stage_encoders([f.wl for f in frames], [f.wr for f in frames], [f.dt for f in frames])
     return cfg, world, lap, ctx, frames, host
 
