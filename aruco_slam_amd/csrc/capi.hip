@@ -25,6 +25,8 @@ using namespace aslam;
 
 namespace {
 
+constexpr int kWinChainFrames = 8;      // frames per chain kernel of a run (its log is replayed meanwhile)
+
 enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
               P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_EKF_MID64, P_EKF_WIN_CHAIN, P_EKF_WIN_SCAN, P_EKF_WIN_FLUSH, P_COUNT };
 const char* kProfNames[P_COUNT] = {"k_threshold", "k_trace", "k_quads", "k_assemble", "k_identify", "k_pose",
@@ -106,6 +108,9 @@ struct aslam_ctx {
     bool win_enabled = true;
     struct Pending { bool active = false; int first = 0, count = 0, ev = 0; } pend;
     hipEvent_t ev_obs[2] = {nullptr, nullptr}, ev_idx = nullptr;
+    hipStream_t stream_win = nullptr;     // scan / flush of the windows, beside the chain on stream_ekf
+    hipEvent_t ev_win[16] = {};
+    unsigned ev_win_next = 0;
     int ev_obs_next = 0;
     bool ev_idx_set = false;
     ObsRaw* h_obs = nullptr;              // pinned: max_batch x kMarkerMax
@@ -398,6 +403,7 @@ int sync_streams(aslam_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->stream_part) HIP_TRY(c, hipStreamSynchronize(c->stream_part));
     HIP_TRY(c, hipStreamSynchronize(c->stream_ekf));
+    if (c->stream_win) HIP_TRY(c, hipStreamSynchronize(c->stream_win));
     c->ekf_count = 0;
     return ASLAM_OK;
 }
@@ -553,6 +559,8 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && hipEventCreateWithFlags(&c->ev_obs[0], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_obs[1], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_idx, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithPriority(&c->stream_win, hipStreamNonBlocking, prio_hi) == hipSuccess;
+    for (int i = 0; i < 16; i++) ok = ok && hipEventCreateWithFlags(&c->ev_win[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_obs), (size_t)B * kMarkerMax * sizeof(ObsRaw), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_nm), (size_t)B * sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_obs_idx), (size_t)B * kWinM, hipHostMallocDefault) == hipSuccess;
@@ -590,6 +598,8 @@ void aslam_destroy(aslam_ctx* c) {
     hipFree(c->d_obs_idx);
     for (int h = 0; h < 2; h++) if (c->ev_obs[h]) hipEventDestroy(c->ev_obs[h]);
     if (c->ev_idx) hipEventDestroy(c->ev_idx);
+    for (int i = 0; i < 16; i++) if (c->ev_win[i]) hipEventDestroy(c->ev_win[i]);
+    if (c->stream_win) { hipStreamSynchronize(c->stream_win); hipStreamDestroy(c->stream_win); }
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->stream_part) hipStreamDestroy(c->stream_part);
     if (c->stream_ekf) hipStreamDestroy(c->stream_ekf);
@@ -720,6 +730,7 @@ int finalize_pending(aslam_ctx* c) {
             }
         }
         if (!clean) {
+            if (std::getenv("ASLAM_DEBUG_PLAN")) std::fprintf(stderr, "plan frame %d: nM %d left to the device\n", f, nM);
             close_window();
             device_plans = true;
             c->mirror_dirty = true;
@@ -753,6 +764,9 @@ int finalize_pending(aslam_ctx* c) {
         c->m_last.swap(nlast);
         const int m = (int)pop.size();
         const bool eligible = predict && n_new == 0 && !any_stationary && m >= 1 && m <= kWinM;
+        if (std::getenv("ASLAM_DEBUG_PLAN"))
+            std::fprintf(stderr, "plan frame %d: nM %d m %d new %d stationary %d predict %d eligible %d (window K %d)\n", f, nM, m, n_new, (int)any_stationary,
+                         (int)predict, (int)eligible, cur.K);
         if (!eligible) {
             close_window();
             Op o{};
@@ -785,16 +799,32 @@ int finalize_pending(aslam_ctx* c) {
             int r = run_ekf_frame(c, o.frame, e[0], e[1], e[2], o.predict);
             if (r) return r;
         } else {
-            hipStream_t st = c->stream_ekf;
-            prof_begin(c, P_EKF_WIN_CHAIN, st);
-            launch_ekf_win_chain(st, c->ekf, c->sp, o.wd, c->d_obs, c->d_nmarkers, c->d_enc, c->d_obs_idx + (size_t)o.wd.first_slot * kWinM);
+            // One run = frames on the same landmarks.  Its chain is cut into pieces of kWinChainFrames frames on the EKF stream;
+            // the replay of each piece's log (scan) and the run's single pass over Sigma (flush) go to a second stream, so
+            // that only the last piece's scan and the flush are not hidden behind the chain.
+            hipStream_t sa = c->stream_ekf, sb = c->stream_win;
+            for (int k0 = 0; k0 < o.wd.K; k0 += kWinChainFrames) {
+                WinDesc sub = o.wd;
+                sub.first_slot = o.wd.first_slot + k0;
+                sub.K = std::min(kWinChainFrames, o.wd.K - k0);
+                sub.cont = k0 > 0 ? 1 : 0;
+                sub.log0 = k0;
+                prof_begin(c, P_EKF_WIN_CHAIN, sa);
+                launch_ekf_win_chain(sa, c->ekf, c->sp, sub, c->d_obs, c->d_nmarkers, c->d_enc, c->d_obs_idx + (size_t)sub.first_slot * kWinM);
+                prof_end(c);
+                hipEvent_t ev = c->ev_win[c->ev_win_next++ & 15];
+                HIP_TRY(c, hipEventRecord(ev, sa));
+                HIP_TRY(c, hipStreamWaitEvent(sb, ev, 0));
+                prof_begin(c, P_EKF_WIN_SCAN, sb);
+                launch_ekf_win_scan(sb, c->ekf, sub);
+                prof_end(c);
+            }
+            prof_begin(c, P_EKF_WIN_FLUSH, sb);
+            launch_ekf_win_flush(sb, c->ekf, o.wd);
             prof_end(c);
-            prof_begin(c, P_EKF_WIN_SCAN, st);
-            launch_ekf_win_scan(st, c->ekf, o.wd);
-            prof_end(c);
-            prof_begin(c, P_EKF_WIN_FLUSH, st);
-            launch_ekf_win_flush(st, c->ekf, o.wd);
-            prof_end(c);
+            hipEvent_t ev = c->ev_win[c->ev_win_next++ & 15];
+            HIP_TRY(c, hipEventRecord(ev, sb));
+            HIP_TRY(c, hipStreamWaitEvent(sa, ev, 0));               // whatever follows on the EKF stream sees the flushed Sigma
             HIP_TRY(c, hipGetLastError());
         }
     }

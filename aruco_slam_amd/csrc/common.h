@@ -6,6 +6,13 @@
 #include <cstdint>
 #include <cstddef>
 
+// Workgroup barrier that orders LDS traffic only: `s_waitcnt lgkmcnt(0)` + `s_barrier`.  __syncthreads() also waits for every
+// outstanding global store (vmcnt(0)), which a kernel that streams a log to HBM between its LDS phases must not pay per barrier.
+// (The CPU emulation used by the tests defines it as its own barrier.)
+#ifndef ASLAM_LDS_BARRIER
+#define ASLAM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 namespace aslam {
 
 constexpr int kScales = 3;        // adaptive-threshold windows 3, 13, 23 (DetectorParameters defaults)

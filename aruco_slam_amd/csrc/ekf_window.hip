@@ -64,6 +64,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
     const int ld = E.ld;
 
     if (blockIdx.x > 0) {
+        if (wd.cont) return;                                       // a run's later chains: X_0, Y_0 are those of its first one
         // ---- X_0^T (row p = column S_p of Sigma) -> d_Wt, Y_0 (row p = row S_p of Sigma) -> d_V, S-position table ----
         const int N = 3 + 3 * (*E.d_L);
         for (int t = (blockIdx.x - 1) * WCT + tid; t < N; t += (gridDim.x - 1) * WCT) {
@@ -88,9 +89,13 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
     for (int e = tid; e < WIMG; e += WCT) { sP[e] = 0.0; sW[e] = 0.0; sV[e] = 0.0; sG[e] = 0.0; }
     __syncthreads();
     if (tid < s) sMu[tid] = E.d_mu[sS[tid]];
-    for (int e = tid; e < s * s; e += WCT) {
-        const int q = e / s, p = e - q * s;                        // column q, row p: consecutive threads walk down a column
-        sP[p * WS + q] = E.d_sigma[(size_t)sS[q] * ld + sS[p]];
+    if (wd.cont) {                                                 // the run goes on: P as the previous chain left it
+        for (int e = tid; e < WIMG; e += WCT) sP[e] = E.d_win_small[WSM_P + e];
+    } else {
+        for (int e = tid; e < s * s; e += WCT) {
+            const int q = e / s, p = e - q * s;                    // column q, row p: consecutive threads walk down a column
+            sP[p * WS + q] = E.d_sigma[(size_t)sS[q] * ld + sS[p]];
+        }
     }
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
 
     for (int k = 0; k < wd.K; k++) {
         const int slot = wd.first_slot + k;
-        double* log = E.d_win_log + (size_t)k * WLOG_STRIDE;
+        double* log = E.d_win_log + (size_t)(wd.log0 + k) * WLOG_STRIDE;
         // ---- 1. predict (aruco_slam.cpp:35-73): pose, H3, Qk ----
         if (tid == 0) {
             const double delta_sl = sp.kl * (e_dt * e_wl), delta_sr = sp.kr * (e_dt * e_wr);
@@ -129,14 +134,14 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
             sincos(th, &sPose[3], &sPose[4]);
             for (int i = 0; i < 9; i++) log[WLOG_H3 + i] = sH3[i];
         }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         if (tid < s) {                                              // rows 0..2 <- H3 * rows 0..2 (every column)
             const double a = sP[tid], b = sP[WS + tid], c = sP[2 * WS + tid];
             sP[tid] = sH3[0] * a + sH3[1] * b + sH3[2] * c;
             sP[WS + tid] = sH3[3] * a + sH3[4] * b + sH3[5] * c;
             sP[2 * WS + tid] = sH3[6] * a + sH3[7] * b + sH3[8] * c;
         }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         if (tid < s) {                                              // columns 0..2 <- columns 0..2 * H3^T (every row), + Qk on the pose block
             double* row = sP + tid * WS;
             const double a = row[0], b = row[1], c = row[2];
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
             int* st = E.d_slot_stat + 4 * slot;
             st[0] = (int)min(n_markers[slot], (unsigned)kMarkerMax); st[1] = 0; st[2] = m; st[3] = 0;
         }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         // the next frame's inputs are fetched while this one is solved
         if (k + 1 < wd.K) {
             if (tid < m) myObs = obs[(size_t)(slot + 1) * kMarkerMax + obs_idx[(size_t)(k + 1) * kWinM + tid]];
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                                                        (Hl[r * 3] * Pd[c] + Hl[r * 3 + 1] * Pd[3 + c] + Hl[r * 3 + 2] * Pd[6 + c]);
                 }
         }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         // ---- 4. innovation matrix A = H W + R (aruco_slam.cpp:146), 3x3 block (bi, bj) in registers; block Gauss-Jordan ----
         double A[9];
         if (act) {
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                 for (int q = 0; q < 9; q++) sPinv[0][q] = Pn[q];
             }
         }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         // pivot block ib IS S_ib = H_ib Sigma_{ib-1} H_ib^T + R_ib; block multiplier F S^-1 of a later row block IS H_bi K_ib
         // (the reference's own recursion, see k_ekf_mid); one barrier per step
         for (int ib = 0; ib < m; ib++) {
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                     for (int q = 0; q < 9; q++) sPinv[cb ^ 1][q] = Pn[q];
                 }
             }
-            __syncthreads();
+            ASLAM_LDS_BARRIER();
         }
         if (act) {                                                  // G = A^-1 into LDS, partial sums of g = G nu
 #pragma unroll
@@ -297,15 +302,16 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
 #pragma unroll
             for (int a = 0; a < 3; a++) sPart[bi][bj][a] = A[a * 3] * n0 + A[a * 3 + 1] * n1 + A[a * 3 + 2] * n2;
         }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         if (tid < n3) {
             const int i = tid / 3, a = tid - 3 * i;
             double acc = 0;
             for (int j = 0; j < m; j++) acc += sPart[i][j][a];
             sg[tid] = acc;
         }
-        // ---- 5. log G, W, V (stores only: they drain while the matrix cores work) ----
-        for (int e = tid; e < WIMG; e += WCT) { log[WLOG_G + e] = sG[e]; log[WLOG_W + e] = sW[e]; log[WLOG_V + e] = sV[e]; }
+        // ---- 5. log V before J replaces it (16-byte stores; nothing in the frame loop waits for global stores: the barriers
+        //         order LDS traffic only) ----
+        for (int e = tid; e < WIMG / 2; e += WCT) reinterpret_cast<double2*>(log + WLOG_V)[e] = reinterpret_cast<const double2*>(sV)[e];
         // ---- 6. J = G V on the f64 matrix cores: wave w owns tile row w >> 1 and two column tiles ----
         const int tr = wave >> 1, tc0 = 2 * (wave & 1);
         {
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
             }
-            __syncthreads();                                        // every wave has read V (and sg is complete)
+            ASLAM_LDS_BARRIER();                                        // every wave has read V (and sg is complete)
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 sV[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li] = acc0[reg];
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
             }
         }
         if (tid < 64) log[WLOG_g + tid] = sg[tid];
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         // ---- 7. P <- P' - W J (aruco_slam.cpp:204 regrouped), mu_S += W g (:203) ----
         {
             v4d acc0, acc1;
@@ -350,10 +356,13 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
             for (int c = 0; c < n3; c++) acc += sW[tid * WS + c] * sg[c];
             sMu[tid] += acc;
         }
-        __syncthreads();
-        // V's image (now J) is rebuilt next frame; its padding must be zero again
-        for (int e = tid; e < WIMG; e += WCT) sV[e] = 0.0;
-        __syncthreads();
+        // log G and W (both stay untouched until the next frame's steps 3 / 4, behind a barrier)
+        for (int e = tid; e < WIMG / 2; e += WCT) {
+            reinterpret_cast<double2*>(log + WLOG_G)[e] = reinterpret_cast<const double2*>(sG)[e];
+            reinterpret_cast<double2*>(log + WLOG_W)[e] = reinterpret_cast<const double2*>(sW)[e];
+        }
+        ASLAM_LDS_BARRIER();
+        // (J's rows >= 3m and columns >= s are exact zeros - G's are - so the image V is rebuilt into next frame needs no clearing)
     }
     // ---- the window's result on S: P_K for the flush, mu_S in place; bookkeeping of the last frame ----
     double* small = E.d_win_small;
@@ -364,36 +373,62 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Replay of the log: workgroup (x = j, y = i) carries Lambda[:, 16j .. 16j+15], Gamma[16i .. 16i+15, :], Psi block (i, j).
+// The next frame's record (G, W, V images: 100 KB) is fetched into registers while the current one is multiplied.
+constexpr int WPF = (3 * WIMG / 2 + 255) / 256;      // 16-byte loads per thread and frame (25)
+constexpr int WSMALL = 64 + 16 + kWinM * 18;         // g, H3 (+ pad), Jacobians
+
 __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
-    __shared__ __align__(16) double sG[WIMG];
-    __shared__ __align__(16) double sW[WIMG];
-    __shared__ __align__(16) double sV[WIMG];
+    __shared__ __align__(16) double sImg[3 * WIMG];      // G, W, V
+    __shared__ __align__(16) double sSmall[WSMALL];      // g | H3 | Hrec
     __shared__ double sLam[64][17];            // Lambda columns (s x 16)
     __shared__ double sGam[16][WS];            // Gamma rows (16 x s)
     __shared__ double sB[64][17], sGB[64][17]; // B = H D Lambda (3m x 16), G B
     __shared__ double sA[16][WS], sAG[16][WS]; // A = Gamma D^T H^T (16 x 3m), A G
-    __shared__ double sPsi[16][17], spsi[16], sgv[64], sH3[9];
-    __shared__ double sHrec[kWinM][18];
+    __shared__ double sPsi[16][17], spsi[16];
+    const double* sG = sImg;
+    const double* sW = sImg + WIMG;
+    const double* sV = sImg + 2 * WIMG;
+    const double* sgv = sSmall;
+    const double* sH3 = sSmall + 64;
+    const double (*sHrec)[18] = reinterpret_cast<const double (*)[18]>(sSmall + 80);
     double (*sPsiPart)[16][16] = reinterpret_cast<double (*)[16][16]>(&sAG[0][0]);   // A G is dead once Gamma has been updated
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int bj = blockIdx.x, bi = blockIdx.y;
     const int m = wd.m, n3 = 3 * m;
-    // Lambda = Gamma = I, Psi = 0, psi = 0
-    for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; sLam[r][c] = (r == 16 * bj + c && r < wd.s) ? 1.0 : 0.0; }
-    for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; sGam[r][c] = (c == 16 * bi + r && c < wd.s) ? 1.0 : 0.0; }
-    for (int e = tid; e < 16 * 16; e += 256) sPsi[e >> 4][e & 15] = 0.0;
-    if (tid < 16) spsi[tid] = 0.0;
+    double* small = E.d_win_small;
+    if (wd.cont) {                                                  // the run goes on: the accumulators as the previous scan left them
+        for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; sLam[r][c] = small[WSM_LAM + r * WS + 16 * bj + c]; }
+        for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; sGam[r][c] = small[WSM_GAM + (16 * bi + r) * WS + c]; }
+        { const int r = tid >> 4, c = tid & 15; sPsi[r][c] = small[WSM_PSI + (16 * bi + r) * WS + 16 * bj + c]; }
+        if (tid < 16) spsi[tid] = small[WSM_psi + 16 * bi + tid];
+    } else {                                                        // Lambda = Gamma = I, Psi = 0, psi = 0
+        for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; sLam[r][c] = (r == 16 * bj + c && r < wd.s) ? 1.0 : 0.0; }
+        for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; sGam[r][c] = (c == 16 * bi + r && c < wd.s) ? 1.0 : 0.0; }
+        for (int e = tid; e < 16 * 16; e += 256) sPsi[e >> 4][e & 15] = 0.0;
+        if (tid < 16) spsi[tid] = 0.0;
+    }
     for (int e = tid; e < 64 * 17; e += 256) { (&sB[0][0])[e] = 0.0; (&sGB[0][0])[e] = 0.0; }
     for (int e = tid; e < 16 * WS; e += 256) { (&sA[0][0])[e] = 0.0; (&sAG[0][0])[e] = 0.0; }
+    double2 pf[WPF], pfs = {0.0, 0.0};
+    {
+        const double* rec = E.d_win_log + (size_t)wd.log0 * WLOG_STRIDE;
+#pragma unroll
+        for (int q = 0; q < WPF; q++) { const int e = tid + 256 * q; if (e < 3 * WIMG / 2) pf[q] = reinterpret_cast<const double2*>(rec)[e]; }
+        if (tid < WSMALL / 2) pfs = reinterpret_cast<const double2*>(rec + WLOG_g)[tid];
+    }
     __syncthreads();
     for (int k = 0; k < wd.K; k++) {
-        const double* log = E.d_win_log + (size_t)k * WLOG_STRIDE;
-        for (int e = tid; e < WIMG; e += 256) { sG[e] = log[WLOG_G + e]; sW[e] = log[WLOG_W + e]; sV[e] = log[WLOG_V + e]; }
-        if (tid < 64) sgv[tid] = log[WLOG_g + tid];
-        if (tid < 9) sH3[tid] = log[WLOG_H3 + tid];
-        for (int e = tid; e < m * 18; e += 256) (&sHrec[0][0])[e] = log[WLOG_HREC + e];
-        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < WPF; q++) { const int e = tid + 256 * q; if (e < 3 * WIMG / 2) reinterpret_cast<double2*>(sImg)[e] = pf[q]; }
+        if (tid < WSMALL / 2) reinterpret_cast<double2*>(sSmall)[tid] = pfs;
+        ASLAM_LDS_BARRIER();
+        if (k + 1 < wd.K) {                                         // in flight while this frame is multiplied
+            const double* rec = E.d_win_log + (size_t)(wd.log0 + k + 1) * WLOG_STRIDE;
+#pragma unroll
+            for (int q = 0; q < WPF; q++) { const int e = tid + 256 * q; if (e < 3 * WIMG / 2) pf[q] = reinterpret_cast<const double2*>(rec)[e]; }
+            if (tid < WSMALL / 2) pfs = reinterpret_cast<const double2*>(rec + WLOG_g)[tid];
+        }
         // D Lambda (rows 0..2) and Gamma D^T (columns 0..2)
         if (tid < 16) {
             const double a = sLam[0][tid], b = sLam[1][tid], c = sLam[2][tid];
@@ -407,7 +442,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
             sGam[r][1] = a * sH3[3] + b * sH3[4] + c * sH3[5];
             sGam[r][2] = a * sH3[6] + b * sH3[7] + c * sH3[8];
         }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         // B[3a+r][c] = Hr_a[r,:] Lambda'[0:3, c] + Hl_a[r,:] Lambda'[3+3a .. , c];   A[r'][3a+r] = Gamma'[r', 0:3] Hr_a[r,:]^T + Gamma'[r', 3+3a ..] Hl_a[r,:]^T
         for (int e = tid; e < n3 * 16; e += 256) {
             const int row = e >> 4, c = e & 15, a = row / 3, r = row - 3 * a;
@@ -421,7 +456,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
             const double* g = sGam[rp];
             sA[rp][col] = (g[0] * h[0] + g[1] * h[1] + g[2] * h[2]) + (g[3 + 3 * a] * h[3] + g[4 + 3 * a] * h[4] + g[5 + 3 * a] * h[5]);
         }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         // GB = G B (wave w: tile row w), AG = A G (wave w: tile column w)
         {
             v4d accB = {0.0, 0.0, 0.0, 0.0}, accA = {0.0, 0.0, 0.0, 0.0};
@@ -434,7 +469,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) { sGB[16 * wave + lk + 4 * reg][li] = accB[reg]; sAG[lk + 4 * reg][16 * wave + li] = accA[reg]; }
         }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         // Lambda -= W GB (wave w: tile row w), Gamma -= AG V (wave w: tile column w), Psi += A GB (depth split over the waves)
         {
             v4d accL, accG, accP = {0.0, 0.0, 0.0, 0.0};
@@ -450,24 +485,21 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
                 const double a3 = sA[li][p0 + lk], b3 = sGB[p0 + lk][li];
                 accP = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, accP, 0, 0, 0);
             }
-            __syncthreads();                                        // every wave has read the old Lambda / Gamma rows it needs (A, B were formed before)
+            double ps = 0;                                          // psi += A g
+            if (tid < 16) for (int c = 0; c < n3; c++) ps += sA[tid][c] * sgv[c];
+            ASLAM_LDS_BARRIER();                                    // every wave is done with A G (its LDS doubles as the Psi partials)
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 sLam[16 * wave + lk + 4 * reg][li] = accL[reg];
                 sGam[lk + 4 * reg][16 * wave + li] = accG[reg];
                 sPsiPart[wave][lk + 4 * reg][li] = accP[reg];
             }
+            if (tid < 16) spsi[tid] += ps;
         }
-        if (tid < 16) {                                             // psi += A g
-            double acc = 0;
-            for (int c = 0; c < n3; c++) acc += sA[tid][c] * sgv[c];
-            spsi[tid] += acc;
-        }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
         { const int r = tid >> 4, c = tid & 15; sPsi[r][c] += (sPsiPart[0][r][c] + sPsiPart[1][r][c]) + (sPsiPart[2][r][c] + sPsiPart[3][r][c]); }
-        __syncthreads();
+        ASLAM_LDS_BARRIER();
     }
-    double* small = E.d_win_small;
     if (bi == 0) for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; small[WSM_LAM + r * WS + 16 * bj + c] = sLam[r][c]; }
     if (bj == 0) for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; small[WSM_GAM + (16 * bi + r) * WS + c] = sGam[r][c]; }
     { const int r = tid >> 4, c = tid & 15; small[WSM_PSI + (16 * bi + r) * WS + 16 * bj + c] = sPsi[r][c]; }

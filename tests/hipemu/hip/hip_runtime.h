@@ -35,6 +35,7 @@
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
 
+struct double2 { double x, y; };
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
@@ -313,6 +314,8 @@ template <class F> void run_grid(const char*, dim3 grid, dim3 block, F&& body) {
     for (auto& x : th) x.join();
 }
 }
+
+#define ASLAM_LDS_BARRIER() __syncthreads()
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::run_grid(#kernel, dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
