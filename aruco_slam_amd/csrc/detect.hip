@@ -288,6 +288,7 @@ __device__ __forceinline__ void walk_step(Walk& w, unsigned m) {
 }
 
 constexpr int kTraceChunk = 256;
+constexpr int kLongWalk = 512;       // steps after which a walk makes its wave stop refilling (see k_trace)
 constexpr int kRunLook = 8;          // pixels of the start candidate's run examined by the two tests below
 
 // A border's canonical start (the state the sequential raster scan starts it from) lies on the FIRST row of the border /
@@ -352,7 +353,11 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
     for (;;) {
         // ---- refill idle lanes from the wave's private ticket range; a new range costs one atomic per kTraceChunk tickets ----
         const unsigned long long idle = __ballot(mode == 0);
-        if (idle != 0ull && !drained) {
+        // A wave that carries a long walk (a border of thousands of pixels is ONE dependent chain of byte loads, and the kernel
+        // cannot end before the longest of them does) stops drawing new ticket ranges: picking candidates up costs every lane
+        // of the wave several dependent loads per iteration, which the long walk would pay on each of its steps.
+        const bool long_walk = __ballot(mode == 1 && n > kLongWalk) != 0ull;
+        if (idle != 0ull && !drained && !(lo == hi && long_walk)) {
             if (lo == hi) {                                       // wave-uniform
                 unsigned base = 0;
                 if (lane == 0) base = atomicAdd(&ctr->q_trace, (unsigned)kTraceChunk);

@@ -36,7 +36,14 @@ constexpr int WLOG_STRIDE = WLOG_HREC + kWinM * 18;     // doubles per logged fr
 constexpr int WSM_LAM = 0, WSM_GAM = WIMG, WSM_PSI = 2 * WIMG, WSM_P = 3 * WIMG, WSM_psi = 4 * WIMG;    // layout of d_win_small
 constexpr int WCT = 512;                      // threads of the chain workgroup
 
-size_t ekf_win_log_doubles() { return (size_t)WLOG_STRIDE * kWinFrames; }
+// development aid (make FLAGS+=-DASLAM_WIN_STAMPS): cycle stamps of the chain's phases, printed for one frame
+#ifdef ASLAM_WIN_STAMPS
+#define WIN_STAMP(i) do { if (tid == 0 && k == 3) stamps[i] = clock64(); } while (0)
+#else
+#define WIN_STAMP(i) do { } while (0)
+#endif
+
+size_t ekf_win_log_doubles() { return (size_t)WLOG_STRIDE * kWinFrames + 512; }   // + slack: the scan stages whole 16-byte x 256-thread passes
 size_t ekf_win_small_doubles() { return (size_t)4 * WIMG + 64; }
 
 __device__ __forceinline__ int win_state_index(const WinDesc& wd, int p) {      // state offset of position p of S
@@ -51,13 +58,11 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
     __shared__ __align__(16) double sW[WIMG];
     __shared__ __align__(16) double sV[WIMG];          // V, later J = G V
     __shared__ __align__(16) double sG[WIMG];
-    __shared__ double sMu[64], sg[64], sZe[64], sNu[64];
+    __shared__ double sMu[64], sZe[64], sNu[64];
     __shared__ double sHr[kWinM][9], sHl[kWinM][9], sRd[kWinM][3];
     __shared__ double sH3[9], sQ[9], sPose[5];
-    __shared__ __align__(16) double sCol[2][kWinM][10];
-    __shared__ __align__(16) double sRow[2][kWinM][10];
-    __shared__ __align__(16) double sPinv[2][10];
-    __shared__ double sPart[kWinM][kWinM][3];
+    __shared__ double sGC[2][64][4];                   // Gauss-Jordan: pivot column block C (64 x 3), double buffered
+    __shared__ double sGR[2][3][WS];                   // pivot row block R (3 x 64)
     __shared__ int sS[64];
     const int tid = threadIdx.x;
     const int m = wd.m, s = wd.s, n3 = 3 * m;
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
     }
 
     // ---- workgroup 0: P = Sigma[S,S] and mu_S into LDS (zero padded to 64) ----
-    if (tid < 64) { sS[tid] = tid < s ? win_state_index(wd, tid) : 0; sMu[tid] = 0.0; sg[tid] = 0.0; }
+    if (tid < 64) { sS[tid] = tid < s ? win_state_index(wd, tid) : 0; sMu[tid] = 0.0; sZe[tid] = 0.0; sNu[tid] = 0.0; }
     for (int e = tid; e < WIMG; e += WCT) { sP[e] = 0.0; sW[e] = 0.0; sV[e] = 0.0; sG[e] = 0.0; }
     __syncthreads();
     if (tid < s) sMu[tid] = E.d_mu[sS[tid]];
@@ -108,9 +113,13 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
     if (tid == 0) { const double* e = enc + (size_t)3 * wd.first_slot; e_wl = e[0]; e_wr = e[1]; e_dt = e[2]; }
     __syncthreads();
 
+#ifdef ASLAM_WIN_STAMPS
+    long long stamps[12] = {0};
+#endif
     for (int k = 0; k < wd.K; k++) {
         const int slot = wd.first_slot + k;
         double* log = E.d_win_log + (size_t)(wd.log0 + k) * WLOG_STRIDE;
+        WIN_STAMP(0);
         // ---- 1. predict (aruco_slam.cpp:35-73): pose, H3, Qk ----
         if (tid == 0) {
             const double delta_sl = sp.kl * (e_dt * e_wl), delta_sr = sp.kr * (e_dt * e_wr);
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
             if (tid < 3) { v0 += sQ[tid * 3]; v1 += sQ[tid * 3 + 1]; v2 += sQ[tid * 3 + 2]; }
             row[0] = v0; row[1] = v1; row[2] = v2;
         }
+        WIN_STAMP(1);
         // ---- 2. records of the m corrections (aruco_slam.cpp:119-143), linearised at the frozen mean ----
         if (tid < m) {
             const int a = tid;
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
             if (tid < m) myObs = obs[(size_t)(slot + 1) * kMarkerMax + obs_idx[(size_t)(k + 1) * kWinM + tid]];
             if (tid == 0) { const double* e = enc + (size_t)3 * (slot + 1); e_wl = e[0]; e_wr = e[1]; e_dt = e[2]; }
         }
+        WIN_STAMP(2);
         // ---- 3. W = P' H^T (s x 3m), V = H P' (3m x s); 3x3 block (i, a): block row / column i of S, correction a ----
         if (tid < (m + 1) * m) {
             const int i = tid / m, a = tid - i * m;
@@ -217,8 +228,8 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                 }
         }
         ASLAM_LDS_BARRIER();
-        // ---- 4. innovation matrix A = H W + R (aruco_slam.cpp:146), 3x3 block (bi, bj) in registers; block Gauss-Jordan ----
-        double A[9];
+        WIN_STAMP(3);
+        // ---- 4. innovation matrix A = H W + R (aruco_slam.cpp:146): thread (bi, bj) forms its 3x3 block into the G image ----
         if (act) {
             double W0[9], W1[9];
 #pragma unroll
@@ -230,107 +241,122 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++)
-                    A[r * 3 + c] = (Hr[r * 3] * W0[c] + Hr[r * 3 + 1] * W0[3 + c] + Hr[r * 3 + 2] * W0[6 + c]) +
-                                   (Hl[r * 3] * W1[c] + Hl[r * 3 + 1] * W1[3 + c] + Hl[r * 3 + 2] * W1[6 + c]);
-            if (bi == bj) { A[0] += sRd[bi][0]; A[4] += sRd[bi][1]; A[8] += sRd[bi][2]; }
-            if (bj == 0) { for (int q = 0; q < 9; q++) sCol[0][bi][q] = A[q]; }
-            if (bi == 0) { for (int q = 0; q < 9; q++) sRow[0][bj][q] = A[q]; }
-            if (bi == 0 && bj == 0) {
-                double Pn[9];
-                inv3_reg(A, Pn);
-                for (int q = 0; q < 9; q++) sPinv[0][q] = Pn[q];
-            }
+                for (int c = 0; c < 3; c++) {
+                    double v = (Hr[r * 3] * W0[c] + Hr[r * 3 + 1] * W0[3 + c] + Hr[r * 3 + 2] * W0[6 + c]) +
+                               (Hl[r * 3] * W1[c] + Hl[r * 3 + 1] * W1[3 + c] + Hl[r * 3 + 2] * W1[6 + c]);
+                    if (bi == bj && r == c) v += sRd[bi][r];
+                    sG[(3 * bi + r) * WS + 3 * bj + c] = v;
+                }
         }
         ASLAM_LDS_BARRIER();
-        // pivot block ib IS S_ib = H_ib Sigma_{ib-1} H_ib^T + R_ib; block multiplier F S^-1 of a later row block IS H_bi K_ib
-        // (the reference's own recursion, see k_ekf_mid); one barrier per step
+        WIN_STAMP(4);
+        // ---- block Gauss-Jordan on the f64 matrix cores.  The 64 x 64 image (A, zero padded) lives in the accumulators: wave w
+        // owns tile row w >> 1 and two column tiles.  Step ib with pivot rows / columns p = 3 ib .. 3 ib + 2, S = A[p,p] (the
+        // reference's S_ib = H_ib Sigma_{ib-1} H_ib^T + R_ib), C = A[:,p], R = A[p,:] is ONE rank-3 product
+        //     A <- A - C~ Y~ ,   C~ = C with rows p replaced by S - I ,   Y~ = S^-1 R with columns p replaced by I + S^-1 ,
+        // which leaves S^-1 in the pivot block, S^-1 R in the pivot rows, -C S^-1 in the pivot columns (= -(H_r K_ib), whose
+        // product with ze_ib the pseudo-innovation nu_r collects, quirk Q1) and the Schur update everywhere else.  Every wave
+        // inverts S itself (no second barrier); C and R of the next pivot are copied out of the accumulators into LDS.
+        // Four waves work (one per SIMD: the step is bound by instruction issue, and two waves on a SIMD would take turns); wave w
+        // owns tile row w and all four column tiles.  The other four only keep the barriers company.
+        const int tr = wave >> 1, tc0 = 2 * (wave & 1);
+        v4d ga[4];
+        if (wave < 4) {
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) ga[t][reg] = sG[(16 * wave + lk + 4 * reg) * WS + 16 * t + li];
+        }
+        if (tid < 64) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) { sGC[0][tid][q] = sG[tid * WS + q]; sGR[0][q][tid] = sG[q * WS + tid]; }
+        }
+        double nu = (tid < n3) ? sZe[tid] : 0.0;                  // wave 0: lane r carries nu_r
+        ASLAM_LDS_BARRIER();
         for (int ib = 0; ib < m; ib++) {
-            const int cb = ib & 1;
-            if (act) {
-                double Pi[9], Y[9];
+            const int cb = ib & 1, p0 = 3 * ib;
+            if (wave < 4) {
+                double Sm[9], Si[9];
 #pragma unroll
-                for (int q = 0; q < 9; q++) Pi[q] = sPinv[cb][q];
-                if (bj == ib) {
+                for (int q = 0; q < 3; q++)
 #pragma unroll
-                    for (int q = 0; q < 9; q++) Y[q] = Pi[q];
-                } else {
-                    double R[9];
-#pragma unroll
-                    for (int q = 0; q < 9; q++) R[q] = sRow[cb][bj][q];
-                    mul3(Pi, R, Y);
+                    for (int c = 0; c < 3; c++) Sm[q * 3 + c] = sGR[cb][q][p0 + c];
+                inv3_fast(Sm, Si);
+                if (wave == 0) {                                    // nu_r += (C_r S^-1) ze_ib for the rows behind the pivot
+                    const double z0 = sZe[p0], z1 = sZe[p0 + 1], z2 = sZe[p0 + 2];
+                    const double u0 = Si[0] * z0 + Si[1] * z1 + Si[2] * z2, u1 = Si[3] * z0 + Si[4] * z1 + Si[5] * z2, u2 = Si[6] * z0 + Si[7] * z1 + Si[8] * z2;
+                    if (tid >= p0 + 3 && tid < n3) nu += sGC[cb][tid][0] * u0 + sGC[cb][tid][1] * u1 + sGC[cb][tid][2] * u2;
                 }
-                if (bi == ib) {
+                // this lane's operands: A[i = row][k] = C~, B[k][j = column] = Y~, k = lk (the 4th depth slot is empty)
+                const int row = 16 * wave + li;
+                double af = lk < 3 ? sGC[cb][row][lk] : 0.0;
+                if (lk < 3 && row - p0 == lk) af -= 1.0;
+                const double s0 = lk == 0 ? Si[0] : (lk == 1 ? Si[3] : Si[6]), s1 = lk == 0 ? Si[1] : (lk == 1 ? Si[4] : Si[7]),
+                             s2 = lk == 0 ? Si[2] : (lk == 1 ? Si[5] : Si[8]);
 #pragma unroll
-                    for (int q = 0; q < 9; q++) A[q] = Y[q];
-                } else {
-                    double F[9];
-#pragma unroll
-                    for (int q = 0; q < 9; q++) F[q] = sCol[cb][bi][q];
-                    if (bj == ib) {
-#pragma unroll
-                        for (int q = 0; q < 9; q++) A[q] = 0.0;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 3; i++)
-#pragma unroll
-                        for (int j = 0; j < 3; j++)
-                            A[i * 3 + j] = fma(-F[i * 3 + 2], Y[6 + j], fma(-F[i * 3 + 1], Y[3 + j], fma(-F[i * 3], Y[j], A[i * 3 + j])));
-                    if (bj == ib && bi > ib) {
-                        const double z0 = sZe[3 * ib], z1 = sZe[3 * ib + 1], z2 = sZe[3 * ib + 2];
-#pragma unroll
-                        for (int a = 0; a < 3; a++) sNu[3 * bi + a] -= A[a * 3] * z0 + A[a * 3 + 1] * z1 + A[a * 3 + 2] * z2;   // nu += (H K) ze, H K = -A
-                    }
+                for (int t = 0; t < 4; t++) {
+                    const int col = 16 * t + li, sc = col - p0;
+                    double v = s0 * sGR[cb][0][col] + s1 * sGR[cb][1][col] + s2 * sGR[cb][2][col];
+                    if (sc >= 0 && sc < 3) v = (sc == lk ? 1.0 : 0.0) + (sc == 0 ? s0 : (sc == 1 ? s1 : s2));
+                    ga[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af, lk < 3 ? v : 0.0, ga[t], 0, 0, 0);
                 }
-                if (bi == ib + 1) { for (int q = 0; q < 9; q++) sRow[cb ^ 1][bj][q] = A[q]; }
-                if (bj == ib + 1) { for (int q = 0; q < 9; q++) sCol[cb ^ 1][bi][q] = A[q]; }
-                if (bi == ib + 1 && bj == ib + 1) {
-                    double Pn[9];
-                    inv3_reg(A, Pn);
+                if (ib + 1 < m) {                                   // C and R of the next pivot, out of the accumulators
+                    const int p1 = p0 + 3;
 #pragma unroll
-                    for (int q = 0; q < 9; q++) sPinv[cb ^ 1][q] = Pn[q];
+                    for (int q = 0; q < 3; q++) {
+                        const int rr = p1 + q;                      // pivot row rr: tile row rr >> 4, register (rr & 15) >> 2, lanes lk == (rr & 3)
+                        if ((rr >> 4) == wave && lk == (rr & 3)) {
+                            const int reg = (rr & 15) >> 2;
+#pragma unroll
+                            for (int t = 0; t < 4; t++)
+                                sGR[cb ^ 1][q][16 * t + li] = reg == 0 ? ga[t][0] : (reg == 1 ? ga[t][1] : (reg == 2 ? ga[t][2] : ga[t][3]));
+                        }
+                        const int cc = p1 + q, tcq = cc >> 4;       // pivot column cc: column tile cc >> 4, lanes li == (cc & 15), all four registers
+                        if (li == (cc & 15)) {
+#pragma unroll
+                            for (int reg = 0; reg < 4; reg++)
+                                sGC[cb ^ 1][16 * wave + lk + 4 * reg][q] = tcq == 0 ? ga[0][reg] : (tcq == 1 ? ga[1][reg] : (tcq == 2 ? ga[2][reg] : ga[3][reg]));
+                        }
+                    }
                 }
             }
             ASLAM_LDS_BARRIER();
         }
-        if (act) {                                                  // G = A^-1 into LDS, partial sums of g = G nu
+        WIN_STAMP(5);
+        // G = A^-1 back into its image; nu beside V (it rides the product J = G V as column 63: g = G nu)
+        if (wave < 4) {
 #pragma unroll
-            for (int a = 0; a < 3; a++)
+            for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int b = 0; b < 3; b++) sG[(3 * bi + a) * WS + 3 * bj + b] = A[a * 3 + b];
-            const double n0 = sNu[3 * bj], n1 = sNu[3 * bj + 1], n2 = sNu[3 * bj + 2];
-#pragma unroll
-            for (int a = 0; a < 3; a++) sPart[bi][bj][a] = A[a * 3] * n0 + A[a * 3 + 1] * n1 + A[a * 3 + 2] * n2;
+                for (int reg = 0; reg < 4; reg++) sG[(16 * wave + lk + 4 * reg) * WS + 16 * t + li] = ga[t][reg];
         }
-        ASLAM_LDS_BARRIER();
-        if (tid < n3) {
-            const int i = tid / 3, a = tid - 3 * i;
-            double acc = 0;
-            for (int j = 0; j < m; j++) acc += sPart[i][j][a];
-            sg[tid] = acc;
-        }
+        if (tid < 64) sNu[tid] = nu;
+        WIN_STAMP(6);
         // ---- 5. log V before J replaces it (16-byte stores; nothing in the frame loop waits for global stores: the barriers
         //         order LDS traffic only) ----
         for (int e = tid; e < WIMG / 2; e += WCT) reinterpret_cast<double2*>(log + WLOG_V)[e] = reinterpret_cast<const double2*>(sV)[e];
-        // ---- 6. J = G V on the f64 matrix cores: wave w owns tile row w >> 1 and two column tiles ----
-        const int tr = wave >> 1, tc0 = 2 * (wave & 1);
+        ASLAM_LDS_BARRIER();
+        WIN_STAMP(7);
+        // ---- 6. J = G V on the f64 matrix cores, same tile ownership; column 63 of V (padding, s <= 63) is nu, so column 63 of J is g ----
         {
             v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            const bool gcol = 16 * tc0 + 16 + li == 63;
             for (int p0 = 0; p0 < 64; p0 += 4) {
                 const double a = sG[(16 * tr + li) * WS + p0 + lk];
-                const double b0 = sV[(p0 + lk) * WS + 16 * tc0 + li], b1 = sV[(p0 + lk) * WS + 16 * tc0 + 16 + li];
+                const double b0 = sV[(p0 + lk) * WS + 16 * tc0 + li], b1 = gcol ? sNu[p0 + lk] : sV[(p0 + lk) * WS + 16 * tc0 + 16 + li];
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
             }
-            ASLAM_LDS_BARRIER();                                        // every wave has read V (and sg is complete)
+            ASLAM_LDS_BARRIER();                                        // every wave has read V
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 sV[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li] = acc0[reg];
                 sV[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + 16 + li] = acc1[reg];
             }
         }
-        if (tid < 64) log[WLOG_g + tid] = sg[tid];
         ASLAM_LDS_BARRIER();
+        if (tid < 64) log[WLOG_g + tid] = sV[tid * WS + 63];
+        WIN_STAMP(8);
         // ---- 7. P <- P' - W J (aruco_slam.cpp:204 regrouped), mu_S += W g (:203) ----
         {
             v4d acc0, acc1;
@@ -351,11 +377,13 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                 sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + 16 + li] = acc1[reg];
             }
         }
-        if (tid < s) {
-            double acc = 0;
-            for (int c = 0; c < n3; c++) acc += sW[tid * WS + c] * sg[c];
-            sMu[tid] += acc;
+        ASLAM_LDS_BARRIER();
+        if (tid < 64) {                                             // column 63 of the product is -(W g): mu_S += W g (aruco_slam.cpp:203)
+            sMu[tid] -= sP[tid * WS + 63];
+            sP[tid * WS + 63] = 0.0;
+            sV[tid * WS + 63] = 0.0;
         }
+        WIN_STAMP(9);
         // log G and W (both stay untouched until the next frame's steps 3 / 4, behind a barrier)
         for (int e = tid; e < WIMG / 2; e += WCT) {
             reinterpret_cast<double2*>(log + WLOG_G)[e] = reinterpret_cast<const double2*>(sG)[e];
@@ -363,7 +391,15 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
         }
         ASLAM_LDS_BARRIER();
         // (J's rows >= 3m and columns >= s are exact zeros - G's are - so the image V is rebuilt into next frame needs no clearing)
+        WIN_STAMP(10);
     }
+#ifdef ASLAM_WIN_STAMPS
+    if (tid == 0 && wd.K > 3) {
+        printf("chain m=%d cycles: predict %lld records %lld barrier+prefetch %lld WV %lld A %lld GJ %lld G,g %lld logV %lld J %lld P,mu %lld logGW %lld | frame %lld\n", m,
+               stamps[1] - stamps[0], stamps[2] - stamps[1], 0LL, stamps[3] - stamps[2], stamps[4] - stamps[3], stamps[5] - stamps[4],
+               stamps[6] - stamps[5], stamps[7] - stamps[6], stamps[8] - stamps[7], stamps[9] - stamps[8], stamps[10] - stamps[9], stamps[10] - stamps[0]);
+    }
+#endif
     // ---- the window's result on S: P_K for the flush, mu_S in place; bookkeeping of the last frame ----
     double* small = E.d_win_small;
     for (int e = tid; e < WIMG; e += WCT) small[WSM_P + e] = sP[e];
@@ -374,23 +410,22 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
 // ---------------------------------------------------------------------------------------------------------------------
 // Replay of the log: workgroup (x = j, y = i) carries Lambda[:, 16j .. 16j+15], Gamma[16i .. 16i+15, :], Psi block (i, j).
 // The next frame's record (G, W, V images: 100 KB) is fetched into registers while the current one is multiplied.
-constexpr int WPF = (3 * WIMG / 2 + 255) / 256;      // 16-byte loads per thread and frame (25)
-constexpr int WSMALL = 64 + 16 + kWinM * 18;         // g, H3 (+ pad), Jacobians
+constexpr int WPF = (WLOG_STRIDE / 2 + 255) / 256;   // 16-byte loads per thread and frame (26): the whole record, unconditionally
+constexpr int WREC = WPF * 256 * 2;                  // doubles staged per frame (a little past the record: the log has slack)
 
 __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
-    __shared__ __align__(16) double sImg[3 * WIMG];      // G, W, V
-    __shared__ __align__(16) double sSmall[WSMALL];      // g | H3 | Hrec
+    __shared__ __align__(16) double sRec[WREC];          // one logged frame: G | W | V | g | H3 | Jacobians
     __shared__ double sLam[64][17];            // Lambda columns (s x 16)
     __shared__ double sGam[16][WS];            // Gamma rows (16 x s)
     __shared__ double sB[64][17], sGB[64][17]; // B = H D Lambda (3m x 16), G B
     __shared__ double sA[16][WS], sAG[16][WS]; // A = Gamma D^T H^T (16 x 3m), A G
     __shared__ double sPsi[16][17], spsi[16];
-    const double* sG = sImg;
-    const double* sW = sImg + WIMG;
-    const double* sV = sImg + 2 * WIMG;
-    const double* sgv = sSmall;
-    const double* sH3 = sSmall + 64;
-    const double (*sHrec)[18] = reinterpret_cast<const double (*)[18]>(sSmall + 80);
+    const double* sG = sRec + WLOG_G;
+    const double* sW = sRec + WLOG_W;
+    const double* sV = sRec + WLOG_V;
+    const double* sgv = sRec + WLOG_g;
+    const double* sH3 = sRec + WLOG_H3;
+    const double (*sHrec)[18] = reinterpret_cast<const double (*)[18]>(sRec + WLOG_HREC);
     double (*sPsiPart)[16][16] = reinterpret_cast<double (*)[16][16]>(&sAG[0][0]);   // A G is dead once Gamma has been updated
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
@@ -410,24 +445,21 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
     }
     for (int e = tid; e < 64 * 17; e += 256) { (&sB[0][0])[e] = 0.0; (&sGB[0][0])[e] = 0.0; }
     for (int e = tid; e < 16 * WS; e += 256) { (&sA[0][0])[e] = 0.0; (&sAG[0][0])[e] = 0.0; }
-    double2 pf[WPF], pfs = {0.0, 0.0};
+    double pfx[WPF], pfy[WPF];
     {
-        const double* rec = E.d_win_log + (size_t)wd.log0 * WLOG_STRIDE;
+        const double2* rec = reinterpret_cast<const double2*>(E.d_win_log + (size_t)wd.log0 * WLOG_STRIDE) + tid;
 #pragma unroll
-        for (int q = 0; q < WPF; q++) { const int e = tid + 256 * q; if (e < 3 * WIMG / 2) pf[q] = reinterpret_cast<const double2*>(rec)[e]; }
-        if (tid < WSMALL / 2) pfs = reinterpret_cast<const double2*>(rec + WLOG_g)[tid];
+        for (int q = 0; q < WPF; q++) { const double2 v = rec[256 * q]; pfx[q] = v.x; pfy[q] = v.y; }
     }
     __syncthreads();
     for (int k = 0; k < wd.K; k++) {
 #pragma unroll
-        for (int q = 0; q < WPF; q++) { const int e = tid + 256 * q; if (e < 3 * WIMG / 2) reinterpret_cast<double2*>(sImg)[e] = pf[q]; }
-        if (tid < WSMALL / 2) reinterpret_cast<double2*>(sSmall)[tid] = pfs;
+        for (int q = 0; q < WPF; q++) { double2 v; v.x = pfx[q]; v.y = pfy[q]; reinterpret_cast<double2*>(sRec)[tid + 256 * q] = v; }
         ASLAM_LDS_BARRIER();
         if (k + 1 < wd.K) {                                         // in flight while this frame is multiplied
-            const double* rec = E.d_win_log + (size_t)(wd.log0 + k + 1) * WLOG_STRIDE;
+            const double2* rec = reinterpret_cast<const double2*>(E.d_win_log + (size_t)(wd.log0 + k + 1) * WLOG_STRIDE) + tid;
 #pragma unroll
-            for (int q = 0; q < WPF; q++) { const int e = tid + 256 * q; if (e < 3 * WIMG / 2) pf[q] = reinterpret_cast<const double2*>(rec)[e]; }
-            if (tid < WSMALL / 2) pfs = reinterpret_cast<const double2*>(rec + WLOG_g)[tid];
+            for (int q = 0; q < WPF; q++) { const double2 v = rec[256 * q]; pfx[q] = v.x; pfy[q] = v.y; }
         }
         // D Lambda (rows 0..2) and Gamma D^T (columns 0..2)
         if (tid < 16) {

@@ -278,7 +278,8 @@ def test_alternating_detection_only_and_full_calls_share_slots_safely():
     b.run_staged(16, 8, with_ekf=True)
     b.sync()
     mu_a, S_a = a.get_state(); mu_b, S_b = b.get_state()
-    assert np.array_equal(mu_a, mu_b) and np.array_equal(S_a, S_b)
+    # (the calls cut the stream into different EKF windows: the same arithmetic regrouped, equal to rounding)
+    assert np.allclose(mu_a, mu_b, rtol=1e-10, atol=1e-13) and np.abs(S_a - S_b).max() <= 1e-10 * np.abs(S_a).max()
     for i in (0, 3, 9, 23):
         da, db = a.get_slot_detections(i), b.get_slot_detections(i)
         assert all(np.array_equal(x, y) for x, y in zip(da, db))
