@@ -39,8 +39,10 @@ constexpr int WCT = 512;                      // threads of the chain workgroup
 // development aid (make FLAGS+=-DASLAM_WIN_STAMPS): cycle stamps of the chain's phases, printed for one frame
 #ifdef ASLAM_WIN_STAMPS
 #define WIN_STAMP(i) do { if (tid == 0 && k == 3) stamps[i] = clock64(); } while (0)
+#define GJ_STAMP(i) do { if (tid == 0 && k == 3 && ib == 5) gst[i] = clock64(); } while (0)
 #else
 #define WIN_STAMP(i) do { } while (0)
+#define GJ_STAMP(i) do { } while (0)
 #endif
 
 size_t ekf_win_log_doubles() { return (size_t)WLOG_STRIDE * kWinFrames + 512; }   // + slack: the scan stages whole 16-byte x 256-thread passes
@@ -115,6 +117,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
 
 #ifdef ASLAM_WIN_STAMPS
     long long stamps[12] = {0};
+    long long gst[10] = {0};
 #endif
     for (int k = 0; k < wd.K; k++) {
         const int slot = wd.first_slot + k;
@@ -257,40 +260,45 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
         // which leaves S^-1 in the pivot block, S^-1 R in the pivot rows, -C S^-1 in the pivot columns (= -(H_r K_ib), whose
         // product with ze_ib the pseudo-innovation nu_r collects, quirk Q1) and the Schur update everywhere else.  Every wave
         // inverts S itself (no second barrier); C and R of the next pivot are copied out of the accumulators into LDS.
-        // Four waves work (one per SIMD: the step is bound by instruction issue, and two waves on a SIMD would take turns); wave w
-        // owns tile row w and all four column tiles.  The other four only keep the barriers company.
-        const int tr = wave >> 1, tc0 = 2 * (wave & 1);
-        v4d ga[4];
-        if (wave < 4) {
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) ga[t][reg] = sG[(16 * wave + lk + 4 * reg) * WS + 16 * t + li];
-        }
+        // The image stays in LDS; waves 0..3 each own one tile row (16 rows x 64 columns) of it - one working wave per SIMD, the
+        // step is bound by the number of instructions issued - and the other four only keep the barriers company.  A wave
+        // reads its operand column C~ from its OWN rows and the pivot rows R from a copy their owner made at the end of the
+        // previous step, so one barrier per step is enough.
         if (tid < 64) {
 #pragma unroll
-            for (int q = 0; q < 3; q++) { sGC[0][tid][q] = sG[tid * WS + q]; sGR[0][q][tid] = sG[q * WS + tid]; }
+            for (int q = 0; q < 3; q++) sGR[0][q][tid] = sG[q * WS + tid];
         }
-        double nu = (tid < n3) ? sZe[tid] : 0.0;                  // wave 0: lane r carries nu_r
+        const int tr = wave >> 1, tc0 = 2 * (wave & 1);           // tile ownership of the two products below (all eight waves)
+        const int gw = wave & 3;                                    // tile row of the working waves
+        const int grow = 16 * gw + li;                              // this lane's operand row
+        double nu = grow < n3 ? sZe[grow] : 0.0;                   // pseudo-innovation of that row (lanes of one row hold copies)
         ASLAM_LDS_BARRIER();
         for (int ib = 0; ib < m; ib++) {
             const int cb = ib & 1, p0 = 3 * ib;
+            GJ_STAMP(0);
             if (wave < 4) {
+                v4d ga[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) ga[t][reg] = sG[(16 * gw + lk + 4 * reg) * WS + 16 * t + li];
                 double Sm[9], Si[9];
 #pragma unroll
                 for (int q = 0; q < 3; q++)
 #pragma unroll
                     for (int c = 0; c < 3; c++) Sm[q * 3 + c] = sGR[cb][q][p0 + c];
+                const double c0 = sG[grow * WS + p0], c1 = sG[grow * WS + p0 + 1], c2 = sG[grow * WS + p0 + 2];     // C of this lane's row
+                GJ_STAMP(1);
                 inv3_fast(Sm, Si);
-                if (wave == 0) {                                    // nu_r += (C_r S^-1) ze_ib for the rows behind the pivot
+                GJ_STAMP(2);
+                {                                                   // nu_r += (C_r S^-1) ze_ib for the rows behind the pivot
                     const double z0 = sZe[p0], z1 = sZe[p0 + 1], z2 = sZe[p0 + 2];
                     const double u0 = Si[0] * z0 + Si[1] * z1 + Si[2] * z2, u1 = Si[3] * z0 + Si[4] * z1 + Si[5] * z2, u2 = Si[6] * z0 + Si[7] * z1 + Si[8] * z2;
-                    if (tid >= p0 + 3 && tid < n3) nu += sGC[cb][tid][0] * u0 + sGC[cb][tid][1] * u1 + sGC[cb][tid][2] * u2;
+                    if (grow >= p0 + 3 && grow < n3) nu += c0 * u0 + c1 * u1 + c2 * u2;
                 }
-                // this lane's operands: A[i = row][k] = C~, B[k][j = column] = Y~, k = lk (the 4th depth slot is empty)
-                const int row = 16 * wave + li;
-                double af = lk < 3 ? sGC[cb][row][lk] : 0.0;
-                if (lk < 3 && row - p0 == lk) af -= 1.0;
+                // operands: A[i = row][k] = C~ (rows p: S - I), B[k][j = column] = Y~ = S^-1 R (columns p: I + S^-1), k = lk
+                double af = lk == 0 ? c0 : (lk == 1 ? c1 : (lk == 2 ? c2 : 0.0));
+                if (lk < 3 && grow - p0 == lk) af -= 1.0;
                 const double s0 = lk == 0 ? Si[0] : (lk == 1 ? Si[3] : Si[6]), s1 = lk == 0 ? Si[1] : (lk == 1 ? Si[4] : Si[7]),
                              s2 = lk == 0 ? Si[2] : (lk == 1 ? Si[5] : Si[8]);
 #pragma unroll
@@ -300,37 +308,28 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                     if (sc >= 0 && sc < 3) v = (sc == lk ? 1.0 : 0.0) + (sc == 0 ? s0 : (sc == 1 ? s1 : s2));
                     ga[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af, lk < 3 ? v : 0.0, ga[t], 0, 0, 0);
                 }
-                if (ib + 1 < m) {                                   // C and R of the next pivot, out of the accumulators
-                    const int p1 = p0 + 3;
+                GJ_STAMP(3);
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int reg = 0; reg < 4; reg++) sG[(16 * gw + lk + 4 * reg) * WS + 16 * t + li] = ga[t][reg];
+                GJ_STAMP(4);
+                __builtin_amdgcn_wave_barrier();                    // (no instruction: the wave's LDS writes above precede the reads below)
+                if (ib + 1 < m) {                                   // the next pivot's rows, copied aside by the wave that owns them
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
-                        const int rr = p1 + q;                      // pivot row rr: tile row rr >> 4, register (rr & 15) >> 2, lanes lk == (rr & 3)
-                        if ((rr >> 4) == wave && lk == (rr & 3)) {
-                            const int reg = (rr & 15) >> 2;
-#pragma unroll
-                            for (int t = 0; t < 4; t++)
-                                sGR[cb ^ 1][q][16 * t + li] = reg == 0 ? ga[t][0] : (reg == 1 ? ga[t][1] : (reg == 2 ? ga[t][2] : ga[t][3]));
-                        }
-                        const int cc = p1 + q, tcq = cc >> 4;       // pivot column cc: column tile cc >> 4, lanes li == (cc & 15), all four registers
-                        if (li == (cc & 15)) {
-#pragma unroll
-                            for (int reg = 0; reg < 4; reg++)
-                                sGC[cb ^ 1][16 * wave + lk + 4 * reg][q] = tcq == 0 ? ga[0][reg] : (tcq == 1 ? ga[1][reg] : (tcq == 2 ? ga[2][reg] : ga[3][reg]));
-                        }
+                        const int rr = p0 + 3 + q;
+                        if ((rr >> 4) == gw) sGR[cb ^ 1][q][lane] = sG[rr * WS + lane];       // LDS is in order per wave: this reads what was just written
                     }
                 }
+                GJ_STAMP(5);
             }
             ASLAM_LDS_BARRIER();
+            GJ_STAMP(6);
         }
         WIN_STAMP(5);
-        // G = A^-1 back into its image; nu beside V (it rides the product J = G V as column 63: g = G nu)
-        if (wave < 4) {
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) sG[(16 * wave + lk + 4 * reg) * WS + 16 * t + li] = ga[t][reg];
-        }
-        if (tid < 64) sNu[tid] = nu;
+        // G = A^-1 is in its image; nu beside V (it rides the product J = G V as column 63: g = G nu)
+        if (wave < 4 && lk == 0) sNu[grow] = nu;
         WIN_STAMP(6);
         // ---- 5. log V before J replaces it (16-byte stores; nothing in the frame loop waits for global stores: the barriers
         //         order LDS traffic only) ----
@@ -395,6 +394,8 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
     }
 #ifdef ASLAM_WIN_STAMPS
     if (tid == 0 && wd.K > 3) {
+        printf("gj step: loads+S %lld inv %lld frags+mfma %lld writeback %lld copy %lld barrier %lld | step %lld\n", gst[1] - gst[0], gst[2] - gst[1], gst[3] - gst[2],
+               gst[4] - gst[3], gst[5] - gst[4], gst[6] - gst[5], gst[6] - gst[0]);
         printf("chain m=%d cycles: predict %lld records %lld barrier+prefetch %lld WV %lld A %lld GJ %lld G,g %lld logV %lld J %lld P,mu %lld logGW %lld | frame %lld\n", m,
                stamps[1] - stamps[0], stamps[2] - stamps[1], 0LL, stamps[3] - stamps[2], stamps[4] - stamps[3], stamps[5] - stamps[4],
                stamps[6] - stamps[5], stamps[7] - stamps[6], stamps[8] - stamps[7], stamps[9] - stamps[8], stamps[10] - stamps[9], stamps[10] - stamps[0]);

@@ -124,7 +124,8 @@ def scene_setup(np, capi, synth, cfg_name, rank, local_rank, args, with_ekf, dow
     cfg = synth.CONFIGS[cfg_name]
     world = synth.PanelWorld(cfg)
     lap = world.lap_length()
-    ctx = capi.Context(device_id=local_rank, max_rows=cfg.rows, max_cols=cfg.cols, max_batch=lap, max_landmarks=world.L + 8,
+    copies = 2                                  # the lap is staged twice: a step of one whole lap alternates between the two slot sets
+    ctx = capi.Context(device_id=local_rank, max_rows=cfg.rows, max_cols=cfg.cols, max_batch=copies * lap, max_landmarks=world.L + 8,
                        persistent_waves=args.waves, ekf_reserved_cus_per_xcd=args.reserve,
                        max_updates_per_frame=24 if world.M <= 24 else 64)
     ctx.set_camera(world.K, np.zeros(5))
@@ -158,7 +159,10 @@ def scene_setup(np, capi, synth, cfg_name, rank, local_rank, args, with_ekf, dow
     if download:
         host = np.stack([ctx.synth_render(i, cfg.rows, cfg.cols, world.K, frames[i].ids, frames[i].poses, noise_amp=2, seed=seeds[i])
                          for i in range(min(download, lap))])
-    ctx.stage_encoders([f.wl for f in frames], [f.wr for f in frames], [f.dt for f in frames])
+    for i in range(lap):                        # second copy of the qualified lap
+        ctx.synth_render(lap + i, cfg.rows, cfg.cols, world.K, frames[i].ids, frames[i].poses, noise_amp=2, seed=seeds[i], download=False)
+    enc = [(f.wl, f.wr, f.dt) for f in frames]
+    ctx.stage_encoders([e[0] for e in enc] * copies, [e[1] for e in enc] * copies, [e[2] for e in enc] * copies)
     return cfg, world, lap, ctx, frames, host
 
 
@@ -176,19 +180,22 @@ def run_config(mods, args, cfg_name, steps, warmup, batch, with_ekf, rank, local
         assert int(st[:, 1].sum()) == world.L, f"map has {int(st[:, 1].sum())} landmarks, expected {world.L}"
         assert (st[:, 0] == world.M).all(), "a frame of the map-building lap lost a marker"
         ctx.stage_encoders([turn.wl], [turn.wr], [turn.dt], slot0=0)
+        ctx.stage_encoders([turn.wl], [turn.wr], [turn.dt], slot0=lap)
         if rank == 0:
             state = (*ctx.get_state(), ctx.get_landmark_ids())
     gather = MapGather(ctx, device=f"cuda:{local_rank}") if want_gather else None
     pos = [0]
 
     def step():
+        # frames in stream order; `pos` runs over the two staged copies of the lap (slot s and slot lap + s hold the same frame)
         first = pos[0]
-        if first + B <= lap:
-            ctx.run_staged(first, B, with_ekf=with_ekf)
-        else:
-            ctx.run_staged(first, lap - first, with_ekf=with_ekf)
-            ctx.run_staged(0, B - (lap - first), with_ekf=with_ekf)
-        pos[0] = (first + B) % lap
+        n = B
+        while n > 0:
+            take = min(n, 2 * lap - first, lap - first % lap)
+            ctx.run_staged(first, take, with_ekf=with_ekf)
+            first = (first + take) % (2 * lap)
+            n -= take
+        pos[0] = first
         if gather is not None:
             gather.gather_pipelined()              # export behind this step's EKF chain, all-gather of the previous step's map
 
@@ -217,7 +224,9 @@ def run_config(mods, args, cfg_name, steps, warmup, batch, with_ekf, rank, local
 
     # ---- every slot's last pass: M detections, M corrections fused, nothing appended, no stationary no-op
     if with_ekf:
-        st = ctx.get_slot_ekf_stats(0, lap)
+        st = ctx.get_slot_ekf_stats(0, 2 * lap)
+        if (warmup + steps) * B < 2 * lap:
+            st = st[:lap]                        # the second copy of the lap was never reached
         ok = (st[:, 0] == world.M) & (st[:, 1] == 0) & (st[:, 2] == world.M) & (st[:, 3] == 0)
         assert ok.all(), f"frames {np.nonzero(~ok)[0][:8].tolist()} did not fuse {world.M} updates: {st[~ok][:4].tolist()}"
     else:
@@ -450,7 +459,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=160, help="frames per step (<= half a lap keeps consecutive steps on disjoint slots)")
+    ap.add_argument("--batch", type=int, default=320, help="frames per step (one lap of the headline scene; the lap is staged twice, so consecutive steps use disjoint slots)")
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--cpu-sample", type=int, default=240, help="frames handed to the CPU oracle (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work per baseline leg")

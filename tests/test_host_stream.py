@@ -28,7 +28,8 @@ def _run(cfg, n_frames, H, zero_copy, waves):
     b.stream_flush()
     mu_a, S_a = a.get_state()
     mu_b, S_b = b.get_state()
-    assert np.array_equal(mu_a, mu_b) and np.array_equal(S_a, S_b)
+    # the two paths cut the stream into different EKF windows (ekf_window.hip): the same arithmetic regrouped, equal to rounding
+    assert np.allclose(mu_a, mu_b, rtol=1e-10, atol=1e-13) and np.abs(S_a - S_b).max() <= 1e-10 * np.abs(S_a).max()
     assert np.array_equal(a.get_landmark_ids(), b.get_landmark_ids())
     da, db = a.get_detections(), b.get_detections()            # last frame
     assert len(da[0]) > 0 and all(np.array_equal(x, y) for x, y in zip(da, db))
