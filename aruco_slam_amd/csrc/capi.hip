@@ -891,6 +891,11 @@ int ring_submit(aslam_ctx* c) {
     const size_t fb = c->in_frame_bytes;
     const int slot0 = h * H;
     if (c->ev_det_set[h]) HIP_TRY(c, hipStreamWaitEvent(c->stream_copy, c->ev_det[h], 0));     // the detector still reads these slots
+    if (c->pend.active && slot0 < c->pend.first + c->pend.count && c->pend.first < slot0 + n) { int rp = finalize_pending(c); if (rp) return rp; }
+    if (c->ekf_count > 0 && slot0 < c->ekf_hi && c->ekf_lo < slot0 + n)
+        HIP_TRY(c, hipStreamWaitEvent(c->stream_copy, c->ev_ekf, 0));                          // EKF work in flight still reads these slots' encoder samples
+    // the encoder samples go to the device as well: the window chain reads them there (ekf_window.hip)
+    HIP_TRY(c, hipMemcpyAsync(c->d_enc + (size_t)3 * slot0, c->ring_enc.data(), (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice, c->stream_copy));
     HIP_TRY(c, hipMemcpyAsync(c->d_in + (size_t)slot0 * fb, c->h_ring + (size_t)slot0 * fb, (size_t)n * fb, hipMemcpyHostToDevice, c->stream_copy));
     HIP_TRY(c, hipEventRecord(c->ev_up[h], c->stream_copy));
     c->ev_up_set[h] = true;

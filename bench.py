@@ -57,7 +57,18 @@ def cpu_worker(spec_path):
     if spec.get("detector"):
         orc.set_detector_params(**spec["detector"])
     o = None
-    if spec["mode"] != "detect":
+    dense = None
+    if spec["mode"] == "dense":
+        # the dense N x N x N products exactly as the reference forms them (aruco_slam.cpp:73, 146, 204), numpy / BLAS standing in
+        # for Eigen; the C++ oracle's `literal` mode skips the exact zeros of Hx and (I - K Gx), which Eigen does not
+        from oracle.ekf_literal import LiteralSlam
+        st = np.load(spec["state"])
+        dense = LiteralSlam()
+        dense.K, dense.D = K, D
+        dense.mu, dense.sigma = st["mu"].copy(), st["sigma"].copy()
+        dense.id_map = {int(i): k for k, i in enumerate(st["ids"])}
+        dense.is_init, dense.last_time = True, 0.0
+    elif spec["mode"] != "detect":
         o = orc.Slam(literal=(spec["mode"] == "literal"))
         o.set_camera(K, D)
         if spec.get("detector"):
@@ -73,7 +84,12 @@ def cpu_worker(spec_path):
         img = np.ascontiguousarray(frames[i])
         wl, wr, dt = enc[i]
         t_now += dt
-        if o is not None:
+        if dense is not None:
+            ids_o, c_o = orc.detect(img)
+            poses = [orc.solve_pnp(c, spec["marker_length"], K, D) for c in c_o]
+            dense.add_encoder(wl, wr, t_now)
+            dense.add_poses(list(ids_o), list(c_o), [p_[0] for p_ in poses], [p_[1] for p_ in poses])
+        elif o is not None:
             o.add_encoder(wl, wr, t_now)
             o.add_image(img)
         else:
@@ -82,7 +98,7 @@ def cpu_worker(spec_path):
                 orc.solve_pnp(c, spec["marker_length"], K, D)
         done += 1
     el = time.perf_counter() - t0
-    n_land = int((o.get_state()[0].size - 3) // 3) if o is not None else 0
+    n_land = int((o.get_state()[0].size - 3) // 3) if o is not None else (int((dense.mu.size - 3) // 3) if dense is not None else 0)
     print(json.dumps({"frames": done, "seconds": el, "landmarks": n_land}), flush=True)
 
 
@@ -296,6 +312,7 @@ def cpu_baseline(np, synth, run, cfg_name, with_ekf, legs_wanted, budget):
             legs.append(("all", mode, ncores, budget, 5))
         if "literal" in legs_wanted and with_ekf:
             legs.append(("literal", "literal", 1, budget, 1))
+            legs.append(("dense", "dense", 1, budget, 2))
         r = run_cpu_legs(tmp, spec, legs)
     finally:
         import shutil
@@ -312,8 +329,12 @@ def cpu_baseline(np, synth, run, cfg_name, with_ekf, legs_wanted, budget):
                             "sample": f"{r['all']['workers']} independent streams (one oracle process each) x ~{r['all']['frames'] // max(r['all']['workers'], 1)} frames, {r['all']['seconds']:.1f} s"}
     if "literal" in r:
         out["literal_ekf"] = {"value": round(r["literal"]["fps"], 3), "cores": 1,
-                              "sample": f"{r['literal']['frames']} frames with the literal dense O(N^3) EKF the reference executes "
-                                        f"(aruco_slam.cpp:73,146,204), {r['literal']['seconds']:.1f} s"}
+                              "sample": f"{r['literal']['frames']} frames with the reference's formulas as written (aruco_slam.cpp:73,146,204), "
+                                        f"C++ loops that skip the exact zeros of Hx and I - K Gx, {r['literal']['seconds']:.1f} s"}
+    if "dense" in r:
+        out["literal_dense_ekf"] = {"value": round(r["dense"]["fps"], 3), "cores": ncores,
+                                    "sample": f"{r['dense']['frames']} frames with the dense N x N x N products the reference executes "
+                                              f"(aruco_slam.cpp:73,146,204; numpy / OpenBLAS on all cores standing in for Eigen), {r['dense']['seconds']:.1f} s"}
     return out
 
 
