@@ -10,6 +10,13 @@
 
 namespace aslam {
 
+// value of lane `src` (wave-uniform) in every lane, through two v_readlane - no LDS traffic, unlike __shfl's ds_bpermute
+#ifndef ASLAM_WAVE_BCAST
+#define ASLAM_WAVE_BCAST(v, src) aslam_wave_bcast(v, src)
+__device__ __forceinline__ double aslam_wave_bcast(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+#endif
 __device__ __forceinline__ double aslam_rcp_estimate(double x) { return ASLAM_RCP_ESTIMATE(x); }
 
 typedef double v4d __attribute__((vector_size(4 * sizeof(double))));   // accumulator of v_mfma_f64_16x16x4_f64

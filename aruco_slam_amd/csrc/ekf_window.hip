@@ -39,7 +39,11 @@ constexpr int WCT = 512;                      // threads of the chain workgroup
 // development aid (make FLAGS+=-DASLAM_WIN_STAMPS): cycle stamps of the chain's phases, printed for one frame
 #ifdef ASLAM_WIN_STAMPS
 #define WIN_STAMP(i) do { if (tid == 0 && k == 3) stamps[i] = clock64(); } while (0)
-#define GJ_STAMP(i) do { if (tid == 0 && k == 3 && ib == 5) gst[i] = clock64(); } while (0)
+#ifdef ASLAM_GJ_STAMPS
+#define GJ_STAMP(i) do { if ((tid & 63) == 0 && k == 3 && j == 5) gst[i] = clock64(); } while (0)
+#else
+#define GJ_STAMP(i) do { } while (0)
+#endif
 #else
 #define WIN_STAMP(i) do { } while (0)
 #define GJ_STAMP(i) do { } while (0)
@@ -47,6 +51,32 @@ constexpr int WCT = 512;                      // threads of the chain workgroup
 
 size_t ekf_win_log_doubles() { return (size_t)WLOG_STRIDE * kWinFrames + 512; }   // + slack: the scan stages whole 16-byte x 256-thread passes
 size_t ekf_win_small_doubles() { return (size_t)4 * WIMG + 64; }
+
+// Gauss-Jordan image layout: element (r, c) of the 64 x 64 image.  Column-major with the rows of every 16-row tile regrouped so
+// that the four rows one lane holds of an MFMA accumulator tile (r = 16 g + lk + 4 reg) are neighbours: 16-byte LDS accesses.
+__device__ __forceinline__ int gpix(int r, int c) { return c * WS + (r & 48) + 4 * (r & 3) + ((r >> 2) & 3); }
+
+// rows p .. p + 2 of the image leave the accumulators of the working wave(s) that own them (row r = 16 g + lk + 4 reg of tile
+// row g): lanes with lk == r & 3 write their register reg = (r >> 2) & 3 of each of the four column tiles.  The register number
+// must be static (a select chain over the accumulators costs more than the rest of the step): one instance per p mod 16.
+template <int P16> __device__ __forceinline__ void gj_publish_rows_at(const v4d (&ga)[4], int p, int gw, int lk, int li, double* rows) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int rl = (P16 + q) & 15;
+        if (gw == ((p + q) >> 4) && lk == (rl & 3)) {
+            double* d = rows + q * 64 + li;
+            d[0] = ga[0][rl >> 2]; d[16] = ga[1][rl >> 2]; d[32] = ga[2][rl >> 2]; d[48] = ga[3][rl >> 2];
+        }
+    }
+}
+__device__ __forceinline__ void gj_publish_rows(const v4d (&ga)[4], int p, int gw, int lk, int li, double* rows) {
+    switch (p & 15) {
+#define ASLAM_GJ_CASE(i) case i: gj_publish_rows_at<i>(ga, p, gw, lk, li, rows); break;
+        ASLAM_GJ_CASE(0) ASLAM_GJ_CASE(1) ASLAM_GJ_CASE(2) ASLAM_GJ_CASE(3) ASLAM_GJ_CASE(4) ASLAM_GJ_CASE(5) ASLAM_GJ_CASE(6) ASLAM_GJ_CASE(7)
+        ASLAM_GJ_CASE(8) ASLAM_GJ_CASE(9) ASLAM_GJ_CASE(10) ASLAM_GJ_CASE(11) ASLAM_GJ_CASE(12) ASLAM_GJ_CASE(13) ASLAM_GJ_CASE(14) ASLAM_GJ_CASE(15)
+#undef ASLAM_GJ_CASE
+    }
+}
 
 __device__ __forceinline__ int win_state_index(const WinDesc& wd, int p) {      // state offset of position p of S
     return p < 3 ? p : wd.li[(p - 3) / 3] + (p - 3) % 3;
@@ -63,8 +93,9 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
     __shared__ double sMu[64], sZe[64], sNu[64];
     __shared__ double sHr[kWinM][9], sHl[kWinM][9], sRd[kWinM][3];
     __shared__ double sH3[9], sQ[9], sPose[5];
-    __shared__ double sGC[2][64][4];                   // Gauss-Jordan: pivot column block C (64 x 3), double buffered
-    __shared__ double sGR[2][3][WS];                   // pivot row block R (3 x 64)
+    __shared__ double sGY[2][4][WS];                   // Gauss-Jordan: a step's B operand Y~ (3 x 64, 4th depth row zero), double buffered
+    __shared__ double sRow[2][4][64];                  // ... and its pivot rows (the column operand by symmetry; 4th row zero)
+    __shared__ double sPub[2][3][64];                  // rows of the pivot after next, as published by the workers that own them
     __shared__ int sS[64];
     const int tid = threadIdx.x;
     const int m = wd.m, s = wd.s, n3 = 3 * m;
@@ -92,7 +123,10 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
     }
 
     // ---- workgroup 0: P = Sigma[S,S] and mu_S into LDS (zero padded to 64) ----
-    if (tid < 64) { sS[tid] = tid < s ? win_state_index(wd, tid) : 0; sMu[tid] = 0.0; sZe[tid] = 0.0; sNu[tid] = 0.0; }
+    if (tid < 64) {
+        sS[tid] = tid < s ? win_state_index(wd, tid) : 0; sMu[tid] = 0.0; sZe[tid] = 0.0; sNu[tid] = 0.0;
+        sGY[0][3][tid] = 0.0; sGY[1][3][tid] = 0.0; sRow[0][3][tid] = 0.0; sRow[1][3][tid] = 0.0;
+    }
     for (int e = tid; e < WIMG; e += WCT) { sP[e] = 0.0; sW[e] = 0.0; sV[e] = 0.0; sG[e] = 0.0; }
     __syncthreads();
     if (tid < s) sMu[tid] = E.d_mu[sS[tid]];
@@ -203,16 +237,34 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
             if (tid == 0) { const double* e = enc + (size_t)3 * (slot + 1); e_wl = e[0]; e_wr = e[1]; e_dt = e[2]; }
         }
         WIN_STAMP(2);
-        // ---- 3. W = P' H^T (s x 3m), V = H P' (3m x s); 3x3 block (i, a): block row / column i of S, correction a ----
+        // ---- 3. W = P' H^T (s x 3m); 3x3 block (i, a): block row i of S, correction a ----
         if (tid < (m + 1) * m) {
             const int i = tid / m, a = tid - i * m;
-            double Pa[9], Pb[9], Pc[9], Pd[9];
+            double Pa[9], Pb[9];
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     Pa[r * 3 + c] = sP[(3 * i + r) * WS + c];                    // P[i, 0]
                     Pb[r * 3 + c] = sP[(3 * i + r) * WS + 3 + 3 * a + c];        // P[i, 1 + a]
+                }
+            const double* Hr = sHr[a];
+            const double* Hl = sHl[a];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    sW[(3 * i + r) * WS + 3 * a + c] = (Pa[r * 3] * Hr[c * 3] + Pa[r * 3 + 1] * Hr[c * 3 + 1] + Pa[r * 3 + 2] * Hr[c * 3 + 2]) +
+                                                       (Pb[r * 3] * Hl[c * 3] + Pb[r * 3 + 1] * Hl[c * 3 + 1] + Pb[r * 3 + 2] * Hl[c * 3 + 2]);
+        }
+        // V = H P' (3m x s) into its image (block (a, i): correction a, block column i of S)
+        if (tid < (m + 1) * m) {
+            const int i = tid / m, a = tid - i * m;
+            double Pc[9], Pd[9];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
                     Pc[r * 3 + c] = sP[r * WS + 3 * i + c];                      // P[0, i]
                     Pd[r * 3 + c] = sP[(3 + 3 * a + r) * WS + 3 * i + c];        // P[1 + a, i]
                 }
@@ -221,14 +273,9 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    // (P[i,0] Hr^T + P[i,1+a] Hl^T)[r][c]
-                    sW[(3 * i + r) * WS + 3 * a + c] = (Pa[r * 3] * Hr[c * 3] + Pa[r * 3 + 1] * Hr[c * 3 + 1] + Pa[r * 3 + 2] * Hr[c * 3 + 2]) +
-                                                       (Pb[r * 3] * Hl[c * 3] + Pb[r * 3 + 1] * Hl[c * 3 + 1] + Pb[r * 3 + 2] * Hl[c * 3 + 2]);
-                    // (Hr P[0,i] + Hl P[1+a,i])[r][c]
+                for (int c = 0; c < 3; c++)
                     sV[(3 * a + r) * WS + 3 * i + c] = (Hr[r * 3] * Pc[c] + Hr[r * 3 + 1] * Pc[3 + c] + Hr[r * 3 + 2] * Pc[6 + c]) +
                                                        (Hl[r * 3] * Pd[c] + Hl[r * 3 + 1] * Pd[3 + c] + Hl[r * 3 + 2] * Pd[6 + c]);
-                }
         }
         ASLAM_LDS_BARRIER();
         WIN_STAMP(3);
@@ -248,88 +295,104 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                     double v = (Hr[r * 3] * W0[c] + Hr[r * 3 + 1] * W0[3 + c] + Hr[r * 3 + 2] * W0[6 + c]) +
                                (Hl[r * 3] * W1[c] + Hl[r * 3 + 1] * W1[3 + c] + Hl[r * 3 + 2] * W1[6 + c]);
                     if (bi == bj && r == c) v += sRd[bi][r];
-                    sG[(3 * bi + r) * WS + 3 * bj + c] = v;
+                    sG[gpix(3 * bi + r, 3 * bj + c)] = v;
                 }
         }
         ASLAM_LDS_BARRIER();
         WIN_STAMP(4);
-        // ---- block Gauss-Jordan on the f64 matrix cores.  The 64 x 64 image (A, zero padded) lives in the accumulators: wave w
-        // owns tile row w >> 1 and two column tiles.  Step ib with pivot rows / columns p = 3 ib .. 3 ib + 2, S = A[p,p] (the
-        // reference's S_ib = H_ib Sigma_{ib-1} H_ib^T + R_ib), C = A[:,p], R = A[p,:] is ONE rank-3 product
+        // ---- block Gauss-Jordan on the f64 matrix cores.  Waves 0..3 ("workers") each keep one tile row (16 rows x 64 columns)
+        // of the 64 x 64 image (A, zero padded) in their accumulators for the whole sweep.  Step j with pivot rows / columns
+        // p = 3 j .. 3 j + 2, S = A[p,p] (the reference's S_j = H_j Sigma_{j-1} H_j^T + R_j), C = A[:,p], R = A[p,:] is ONE
+        // rank-3 product
         //     A <- A - C~ Y~ ,   C~ = C with rows p replaced by S - I ,   Y~ = S^-1 R with columns p replaced by I + S^-1 ,
-        // which leaves S^-1 in the pivot block, S^-1 R in the pivot rows, -C S^-1 in the pivot columns (= -(H_r K_ib), whose
-        // product with ze_ib the pseudo-innovation nu_r collects, quirk Q1) and the Schur update everywhere else.  Every wave
-        // inverts S itself (no second barrier); C and R of the next pivot are copied out of the accumulators into LDS.
-        // The image stays in LDS; waves 0..3 each own one tile row (16 rows x 64 columns) of it - one working wave per SIMD, the
-        // step is bound by the number of instructions issued - and the other four only keep the barriers company.  A wave
-        // reads its operand column C~ from its OWN rows and the pivot rows R from a copy their owner made at the end of the
-        // previous step, so one barrier per step is enough.
-        if (tid < 64) {
-#pragma unroll
-            for (int q = 0; q < 3; q++) sGR[0][q][tid] = sG[q * WS + tid];
-        }
+        // which leaves S^-1 in the pivot block, S^-1 R in the pivot rows, -C S^-1 in the pivot columns (= -(H_r K_j), whose
+        // product with ze_j the pseudo-innovation nu_r collects, quirk Q1) and the Schur update everywhere else.
+        // A step is a chain of dependent LDS round trips and cross-lane moves, not arithmetic (measured), so
+        //  * only the three pivot ROWS ever leave the accumulators: the partially inverted image stays symmetric up to the sign
+        //    of the pivoted/unpivoted cross blocks (A is symmetric to rounding), so C[r][k] = +-R[k][r] and the column operand
+        //    is read from the same three rows;
+        //  * wave 4 prepares pivot j + 1 WHILE the workers apply step j: the workers publish the rows of pivot j + 2 as they
+        //    stand after step j; one phase later wave 4 applies step j + 1's rank-3 correction to those three rows itself, from
+        //    the rows and Y~ of pivot j + 1 it still holds in registers (lane = column; uniform values by v_readlane, no LDS),
+        //    inverts S and hands Y~ and the corrected rows to the workers.  One barrier per step.
         const int tr = wave >> 1, tc0 = 2 * (wave & 1);           // tile ownership of the two products below (all eight waves)
         const int gw = wave & 3;                                    // tile row of the working waves
         const int grow = 16 * gw + li;                              // this lane's operand row
-        double nu = grow < n3 ? sZe[grow] : 0.0;                   // pseudo-innovation of that row (lanes of one row hold copies)
-        ASLAM_LDS_BARRIER();
-        for (int ib = 0; ib < m; ib++) {
-            const int cb = ib & 1, p0 = 3 * ib;
-            GJ_STAMP(0);
-            if (wave < 4) {
-                v4d ga[4];
+        double nu = (wave == 4 && lane < n3) ? sZe[lane] : 0.0;     // wave 4: innovation / pseudo-innovation of row `lane`
+        const double ze = nu;
+        double Rp0 = 0.0, Rp1 = 0.0, Rp2 = 0.0, Yp0 = 0.0, Yp1 = 0.0, Yp2 = 0.0;      // wave 4: rows and Y~ of the pivot prepared last
+        v4d ga[4];
+        if (wave < 4) {
 #pragma unroll
-                for (int t = 0; t < 4; t++)
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) ga[t][reg] = sG[(16 * gw + lk + 4 * reg) * WS + 16 * t + li];
-                double Sm[9], Si[9];
-#pragma unroll
-                for (int q = 0; q < 3; q++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) Sm[q * 3 + c] = sGR[cb][q][p0 + c];
-                const double c0 = sG[grow * WS + p0], c1 = sG[grow * WS + p0 + 1], c2 = sG[grow * WS + p0 + 2];     // C of this lane's row
-                GJ_STAMP(1);
-                inv3_fast(Sm, Si);
-                GJ_STAMP(2);
-                {                                                   // nu_r += (C_r S^-1) ze_ib for the rows behind the pivot
-                    const double z0 = sZe[p0], z1 = sZe[p0 + 1], z2 = sZe[p0 + 2];
-                    const double u0 = Si[0] * z0 + Si[1] * z1 + Si[2] * z2, u1 = Si[3] * z0 + Si[4] * z1 + Si[5] * z2, u2 = Si[6] * z0 + Si[7] * z1 + Si[8] * z2;
-                    if (grow >= p0 + 3 && grow < n3) nu += c0 * u0 + c1 * u1 + c2 * u2;
-                }
-                // operands: A[i = row][k] = C~ (rows p: S - I), B[k][j = column] = Y~ = S^-1 R (columns p: I + S^-1), k = lk
-                double af = lk == 0 ? c0 : (lk == 1 ? c1 : (lk == 2 ? c2 : 0.0));
-                if (lk < 3 && grow - p0 == lk) af -= 1.0;
-                const double s0 = lk == 0 ? Si[0] : (lk == 1 ? Si[3] : Si[6]), s1 = lk == 0 ? Si[1] : (lk == 1 ? Si[4] : Si[7]),
-                             s2 = lk == 0 ? Si[2] : (lk == 1 ? Si[5] : Si[8]);
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int col = 16 * t + li, sc = col - p0;
-                    double v = s0 * sGR[cb][0][col] + s1 * sGR[cb][1][col] + s2 * sGR[cb][2][col];
-                    if (sc >= 0 && sc < 3) v = (sc == lk ? 1.0 : 0.0) + (sc == 0 ? s0 : (sc == 1 ? s1 : s2));
-                    ga[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(-af, lk < 3 ? v : 0.0, ga[t], 0, 0, 0);
-                }
-                GJ_STAMP(3);
-#pragma unroll
-                for (int t = 0; t < 4; t++)
-#pragma unroll
-                    for (int reg = 0; reg < 4; reg++) sG[(16 * gw + lk + 4 * reg) * WS + 16 * t + li] = ga[t][reg];
-                GJ_STAMP(4);
-                __builtin_amdgcn_wave_barrier();                    // (no instruction: the wave's LDS writes above precede the reads below)
-                if (ib + 1 < m) {                                   // the next pivot's rows, copied aside by the wave that owns them
-#pragma unroll
-                    for (int q = 0; q < 3; q++) {
-                        const int rr = p0 + 3 + q;
-                        if ((rr >> 4) == gw) sGR[cb ^ 1][q][lane] = sG[rr * WS + lane];       // LDS is in order per wave: this reads what was just written
-                    }
-                }
-                GJ_STAMP(5);
+            for (int t = 0; t < 4; t++) {
+                const double2 lo = *reinterpret_cast<const double2*>(&sG[(16 * t + li) * WS + 16 * gw + 4 * lk]);
+                const double2 hi = *reinterpret_cast<const double2*>(&sG[(16 * t + li) * WS + 16 * gw + 4 * lk + 2]);
+                ga[t][0] = lo.x; ga[t][1] = lo.y; ga[t][2] = hi.x; ga[t][3] = hi.y;
             }
+            gj_publish_rows(ga, 0, gw, lk, li, &sPub[0][0][0]);
+            if (m > 1) gj_publish_rows(ga, 3, gw, lk, li, &sPub[1][0][0]);
+        }
+        ASLAM_LDS_BARRIER();
+        for (int j = -1; j < m; j++) {
+            // phase j: the workers apply step j and publish the rows of pivot j + 2; wave 4 prepares pivot j + 1
+            GJ_STAMP(0);
+            if (wave == 4) {
+                if (j + 1 < m) {
+                    const int jb = (j + 1) & 1, p = 3 * (j + 1);
+                    double R0 = sPub[jb][0][lane], R1 = sPub[jb][1][lane], R2 = sPub[jb][2][lane];     // rows of pivot j + 1 as of step j - 1
+                    if (j >= 0) {
+                        // step j's correction of these rows: C~_j[p + q][k] = R_j[k][p + q] (rows behind pivot j), Y~_j from the registers
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            const double c0 = ASLAM_WAVE_BCAST(Rp0, p + q), c1 = ASLAM_WAVE_BCAST(Rp1, p + q), c2 = ASLAM_WAVE_BCAST(Rp2, p + q);
+                            double& R = q == 0 ? R0 : q == 1 ? R1 : R2;
+                            R = fma(-c2, Yp2, fma(-c1, Yp1, fma(-c0, Yp0, R)));
+                        }
+                    }
+                    double Sm[9], Si[9];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { Sm[c] = ASLAM_WAVE_BCAST(R0, p + c); Sm[3 + c] = ASLAM_WAVE_BCAST(R1, p + c); Sm[6 + c] = ASLAM_WAVE_BCAST(R2, p + c); }
+                    inv3_fast(Sm, Si);
+                    const double r0 = R0 + (lane == p ? 1.0 : 0.0), r1 = R1 + (lane == p + 1 ? 1.0 : 0.0), r2 = R2 + (lane == p + 2 ? 1.0 : 0.0);   // R~
+                    Yp0 = fma(Si[2], r2, fma(Si[1], r1, Si[0] * r0));
+                    Yp1 = fma(Si[5], r2, fma(Si[4], r1, Si[3] * r0));
+                    Yp2 = fma(Si[8], r2, fma(Si[7], r1, Si[6] * r0));
+                    sGY[jb][0][lane] = Yp0; sGY[jb][1][lane] = Yp1; sGY[jb][2][lane] = Yp2;
+                    sRow[jb][0][lane] = R0; sRow[jb][1][lane] = R1; sRow[jb][2][lane] = R2;
+                    Rp0 = R0; Rp1 = R1; Rp2 = R2;
+                    // nu_r += (C_r S^-1) ze_p for the rows behind the pivot: C[r][k] = R[k][r] there, u = S^-1 ze_p
+                    const double z0 = ASLAM_WAVE_BCAST(ze, p), z1 = ASLAM_WAVE_BCAST(ze, p + 1), z2 = ASLAM_WAVE_BCAST(ze, p + 2);
+                    const double u0 = fma(Si[2], z2, fma(Si[1], z1, Si[0] * z0)), u1 = fma(Si[5], z2, fma(Si[4], z1, Si[3] * z0)), u2 = fma(Si[8], z2, fma(Si[7], z1, Si[6] * z0));
+                    if (lane >= p + 3 && lane < n3) nu += R0 * u0 + R1 * u1 + R2 * u2;
+                }
+            } else if (wave < 4 && j >= 0) {
+                // ---- apply step j: A <- A - C~ Y~ on this wave's tile row.  A operand C~[row][k = lk] from the pivot rows: rows
+                // already pivoted carry the opposite sign, the pivot rows themselves S - I; depth 3 is the zero row ----
+                const int cb = j & 1, p0 = 3 * j;
+                const double rr = sRow[cb][lk][grow];
+                double af = grow < p0 ? rr : -rr;                   // = -C~
+                if (lk < 3 && grow == p0 + lk) af += 1.0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) ga[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, sGY[cb][lk][16 * t + li], ga[t], 0, 0, 0);
+                if (j + 2 < m) gj_publish_rows(ga, p0 + 6, gw, lk, li, &sPub[cb][0][0]);
+            }
+            GJ_STAMP(1);
             ASLAM_LDS_BARRIER();
-            GJ_STAMP(6);
+            GJ_STAMP(2);
         }
         WIN_STAMP(5);
-        // G = A^-1 is in its image; nu beside V (it rides the product J = G V as column 63: g = G nu)
-        if (wave < 4 && lk == 0) sNu[grow] = nu;
+        // G = A^-1 into its image (gpix layout: a lane's four rows of a tile are neighbours); nu beside V (it rides the
+        // product J = G V as column 63: g = G nu)
+        if (wave < 4) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                double2 lo, hi;
+                lo.x = ga[t][0]; lo.y = ga[t][1]; hi.x = ga[t][2]; hi.y = ga[t][3];
+                *reinterpret_cast<double2*>(&sG[(16 * t + li) * WS + 16 * gw + 4 * lk]) = lo;
+                *reinterpret_cast<double2*>(&sG[(16 * t + li) * WS + 16 * gw + 4 * lk + 2]) = hi;
+            }
+        } else if (wave == 4) sNu[lane] = nu;
+        ASLAM_LDS_BARRIER();
         WIN_STAMP(6);
         // ---- 5. log V before J replaces it (16-byte stores; nothing in the frame loop waits for global stores: the barriers
         //         order LDS traffic only) ----
@@ -341,7 +404,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
             v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
             const bool gcol = 16 * tc0 + 16 + li == 63;
             for (int p0 = 0; p0 < 64; p0 += 4) {
-                const double a = sG[(16 * tr + li) * WS + p0 + lk];
+                const double a = sG[gpix(16 * tr + li, p0 + lk)];
                 const double b0 = sV[(p0 + lk) * WS + 16 * tc0 + li], b1 = gcol ? sNu[p0 + lk] : sV[(p0 + lk) * WS + 16 * tc0 + 16 + li];
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
@@ -384,17 +447,20 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
         }
         WIN_STAMP(9);
         // log G and W (both stay untouched until the next frame's steps 3 / 4, behind a barrier)
-        for (int e = tid; e < WIMG / 2; e += WCT) {
-            reinterpret_cast<double2*>(log + WLOG_G)[e] = reinterpret_cast<const double2*>(sG)[e];
-            reinterpret_cast<double2*>(log + WLOG_W)[e] = reinterpret_cast<const double2*>(sW)[e];
-        }
+        for (int e = tid; e < WIMG / 2; e += WCT) reinterpret_cast<double2*>(log + WLOG_W)[e] = reinterpret_cast<const double2*>(sW)[e];
+        for (int e = tid; e < 64 * 64; e += WCT) log[WLOG_G + (e >> 6) * WS + (e & 63)] = sG[gpix(e >> 6, e & 63)];      // G leaves in row-major order
         ASLAM_LDS_BARRIER();
         // (J's rows >= 3m and columns >= s are exact zeros - G's are - so the image V is rebuilt into next frame needs no clearing)
         WIN_STAMP(10);
     }
 #ifdef ASLAM_WIN_STAMPS
+#ifdef ASLAM_GJ_STAMPS
+    if ((tid & 63) == 0 && wd.K > 3) {
+        printf("tid %d gj step: work %lld barrier %lld\n", tid, gst[1] - gst[0], gst[2] - gst[1]);
+    }
+#endif
     if (tid == 0 && wd.K > 3) {
-        printf("gj step: loads+S %lld inv %lld frags+mfma %lld writeback %lld copy %lld barrier %lld | step %lld\n", gst[1] - gst[0], gst[2] - gst[1], gst[3] - gst[2],
+        if (false) printf("gj step: loads+S %lld inv %lld frags+mfma %lld writeback %lld copy %lld barrier %lld | step %lld\n", gst[1] - gst[0], gst[2] - gst[1], gst[3] - gst[2],
                gst[4] - gst[3], gst[5] - gst[4], gst[6] - gst[5], gst[6] - gst[0]);
         printf("chain m=%d cycles: predict %lld records %lld barrier+prefetch %lld WV %lld A %lld GJ %lld G,g %lld logV %lld J %lld P,mu %lld logGW %lld | frame %lld\n", m,
                stamps[1] - stamps[0], stamps[2] - stamps[1], 0LL, stamps[3] - stamps[2], stamps[4] - stamps[3], stamps[5] - stamps[4],

@@ -319,6 +319,7 @@ template <class F> void run_grid(const char*, dim3 grid, dim3 block, F&& body) {
 
 #define ASLAM_LDS_BARRIER() __syncthreads()
 #define ASLAM_RCP_ESTIMATE(x) (1.0 / (x))
+#define ASLAM_WAVE_BCAST(v, src) __shfl(v, src)
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::run_grid(#kernel, dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
