@@ -45,6 +45,11 @@ __device__ __forceinline__ unsigned box_mean_r(const unsigned (*I)[LW + 1], int 
     return (2u * sum + k2) / (2u * k2);
 }
 
+#ifdef ASLAM_THR_STAMPS
+#define THR_STAMP(i) do { if (tid == 0 && blockIdx.x == 4000) tst[i] = clock64(); } while (0)
+#else
+#define THR_STAMP(i) do { } while (0)
+#endif
 template <bool kDefaultWindows>
 __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ in, int channels, size_t in_frame_stride,
                                                    size_t in_row_step, uint8_t* __restrict__ gray_out,
@@ -53,7 +58,9 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                                                    Counters* ctr, int nframes) {
     __shared__ uint8_t g[LH][LW];
     __shared__ unsigned I[LH + 1][LW + 1];
-    __shared__ uint8_t bin[TH + 2][TW + 2];
+    __shared__ unsigned long long sRow[kScales][TH + 2];     // threshold decisions of ring row by, columns x0 - 1 .. x0 + 62 (bit = column)
+    __shared__ unsigned long long sRing[kScales][2];         // ... of columns x0 + 63 and x0 + 64 (bit = ring row)
+    __shared__ unsigned short sLut[512];
     __shared__ unsigned sStart[kBlockStarts];      // x | y << 12 | scale << 24 | type << 26
     __shared__ unsigned sNStart, sBase;
 
@@ -70,24 +77,41 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
     const unsigned rem = logical - (unsigned)b * gx * gy;
     const int x0 = (int)(rem % gx) * TW, y0 = (int)(rem / gx) * TH;
     const uint8_t* src = in + (size_t)b * in_frame_stride;
+#ifdef ASLAM_THR_STAMPS
+    long long tst[8] = {0};
+#endif
     if (tid == 0) sNStart = 0;
+    THR_STAMP(0);
 
     // 1. gray tile with replicated border (BORDER_REPLICATE of the box filter)
     if (channels == 1 && (in_row_step & 3) == 0 && ((size_t)src & 3) == 0) {
-        // 4 pixels per load where the dword lies inside the row; LW = 88 = 22 dwords per tile row
-        for (int i = tid; i < LH * (LW / 4); i += 256) {
-            int ly = i / (LW / 4), q = i - ly * (LW / 4);
-            int gy = min(max(y0 + ly - HALO, 0), rows - 1);
-            int gx = x0 + 4 * q - HALO;
-            const uint8_t* rowp = src + (size_t)gy * in_row_step;
-            unsigned v;
-            if (gx >= 0 && gx + 3 < cols) {
-                v = *reinterpret_cast<const unsigned*>(rowp + gx);
-            } else {
-                v = 0;
-                for (int k = 0; k < 4; k++) v |= (unsigned)rowp[min(max(gx + k, 0), cols - 1)] << (8 * k);
+        // 4 pixels per load where the dword lies inside the row; LW = 88 = 22 dwords per tile row.  All of a thread's loads are
+        // issued before the first of them is stored: one memory latency per tile, not one per pass
+        constexpr int kPasses = (LH * (LW / 4) + 255) / 256;
+        unsigned v[kPasses];
+#pragma unroll
+        for (int p = 0; p < kPasses; p++) {
+            const int i = tid + 256 * p;
+            v[p] = 0;
+            if (i < LH * (LW / 4)) {
+                const int ly = i / (LW / 4), q = i - ly * (LW / 4);
+                const int gy = min(max(y0 + ly - HALO, 0), rows - 1);
+                const int gx = x0 + 4 * q - HALO;
+                const uint8_t* rowp = src + (size_t)gy * in_row_step;
+                if (gx >= 0 && gx + 3 < cols) {
+                    v[p] = *reinterpret_cast<const unsigned*>(rowp + gx);
+                } else {
+                    for (int k = 0; k < 4; k++) v[p] |= (unsigned)rowp[min(max(gx + k, 0), cols - 1)] << (8 * k);
+                }
             }
-            *reinterpret_cast<unsigned*>(&g[ly][4 * q]) = v;
+        }
+#pragma unroll
+        for (int p = 0; p < kPasses; p++) {
+            const int i = tid + 256 * p;
+            if (i < LH * (LW / 4)) {
+                const int ly = i / (LW / 4), q = i - ly * (LW / 4);
+                *reinterpret_cast<unsigned*>(&g[ly][4 * q]) = v[p];
+            }
         }
     } else {
         for (int i = tid; i < LH * LW; i += 256) {
@@ -102,6 +126,7 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         }
     }
     __syncthreads();
+    THR_STAMP(1);
 
     // tight gray plane for the bit-extraction stage (skipped when the input already is one)
     if (gray_out != nullptr) {
@@ -145,15 +170,18 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         }
     }
     __syncthreads();
+    THR_STAMP(2);
 
-    // 3. three thresholds (windows 3 / 13 / 23) for the tile plus a 1-px ring (needed by the neighbour masks)
-    for (int i = tid; i < (TH + 2) * (TW + 2); i += 256) {
-        int by = i / (TW + 2), bx = i - by * (TW + 2);
-        int gx = x0 + bx - 1, gy = y0 + by - 1;
+    // 3. three thresholds (windows 3 / 13 / 23) for the tile plus a 1-px ring (needed by the neighbour masks), kept as BIT ROWS:
+    //    a wave thresholds one 64-pixel row per pass and the row's 64 decisions per scale are one ballot.  Ring coordinates:
+    //    row by = 0 .. TH + 1 is image row y0 + by - 1, bit e = 0 .. TW + 1 of a row is image column x0 + e - 1; bits 0 .. 63 live in
+    //    sRow[.][by][0] (columns x0 - 1 .. x0 + 62), the last two columns in sRing (one ballot over the rows each).
+    auto thr_bits = [&](int by, int bx) -> unsigned {
+        const int gx = x0 + bx - 1, gy = y0 + by - 1;
         unsigned bits = 0;
         if (gx >= 0 && gx < cols && gy >= 0 && gy < rows) {
-            int lx = bx - 1 + HALO, ly = by - 1 + HALO;
-            int v = g[ly][lx];
+            const int lx = bx - 1 + HALO, ly = by - 1 + HALO;
+            const int v = g[ly][lx];
             if (kDefaultWindows) {
                 if (v - (int)box_mean<1>(I, ly, lx) <= -cfg.thresh_c) bits |= 1u;
                 if (v - (int)box_mean<6>(I, ly, lx) <= -cfg.thresh_c) bits |= 2u;
@@ -164,43 +192,82 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                     if (s < cfg.n_scales && v - (int)box_mean_r(I, ly, lx, cfg.win_r[s]) <= -cfg.thresh_c) bits |= 1u << s;
             }
         }
-        bin[by][bx] = (uint8_t)bits;
+        return bits;
+    };
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int by = wave; by < TH + 2; by += 4) {
+            const unsigned bits = thr_bits(by, lane);
+#pragma unroll
+            for (int s = 0; s < kScales; s++) {
+                const unsigned long long row = __ballot((bits >> s) & 1u);
+                if (lane == 0) sRow[s][by] = row;
+            }
+        }
+        if (wave < 2) {                                             // columns TW and TW + 1 of the ring: lane = row
+            const unsigned bits = lane < TH + 2 ? thr_bits(lane, TW + wave) : 0u;
+#pragma unroll
+            for (int s = 0; s < kScales; s++) {
+                const unsigned long long col = __ballot((bits >> s) & 1u);
+                if (lane == 0) sRing[s][wave] = col;
+            }
+        }
+        // neighbourhood table: index = N3 | C3 << 3 | S3 << 6 (three pixels west..east of the rows above / at / below) ->
+        // bits 0..7 the neighbour mask (bit d = neighbour in direction d is foreground; 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE),
+        // bit 8 outer-type start (foreground, W/NW/N/NE background, not isolated), bit 9 hole-type start (background, W and N foreground)
+        for (int i = tid; i < 512; i += 256) {
+            const unsigned n3 = i & 7u, c3 = (i >> 3) & 7u, s3 = (unsigned)i >> 6;
+            const unsigned m = ((c3 >> 2) & 1u) | (((n3 >> 2) & 1u) << 1) | (((n3 >> 1) & 1u) << 2) | ((n3 & 1u) << 3) | ((c3 & 1u) << 4) |
+                               ((s3 & 1u) << 5) | (((s3 >> 1) & 1u) << 6) | (((s3 >> 2) & 1u) << 7);
+            const unsigned fg = (c3 >> 1) & 1u;
+            const bool outer = fg && m != 0 && (m & 0x1Eu) == 0;
+            const bool hole = !fg && (m & 0x14u) == 0x14u;
+            sLut[i] = (unsigned short)(m | (outer ? 0x100u : 0u) | (hole ? 0x200u : 0u));
+        }
     }
     __syncthreads();
+    THR_STAMP(3);
 
-    // 4. neighbour masks (bit d = neighbour in direction d is foreground; 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE)
-    //    and border start candidates (staged in LDS, one reservation per tile in the frame's list)
+    // 4. neighbour masks and border start candidates (staged in LDS, one reservation per tile in the frame's list): a thread
+    //    takes four pixels of a row; six consecutive bits of the three bit rows around them index the table above
     for (int u = tid; u < TH * TW / 4; u += 256) {
-        int ty = u / (TW / 4), tx4 = (u - ty * (TW / 4)) * 4;
-        int gy = y0 + ty;
+        const int ty = u / (TW / 4), tx4 = (u - ty * (TW / 4)) * 4;
+        const int gy = y0 + ty;
         unsigned out[kScales] = {0, 0, 0};
-        for (int j = 0; j < 4; j++) {
-            int tx = tx4 + j, gx = x0 + tx;
-            if (gx < cols && gy < rows) {
-                unsigned c = bin[ty + 1][tx + 1];
-                unsigned e = bin[ty + 1][tx + 2], ne = bin[ty][tx + 2], n = bin[ty][tx + 1], nw = bin[ty][tx];
-                unsigned w = bin[ty + 1][tx], sw = bin[ty + 2][tx], so = bin[ty + 2][tx + 1], se = bin[ty + 2][tx + 2];
+        unsigned cand = 0;                                          // bit 4 s + j: outer-type start at pixel j of scale s; bit 16 + 4 s + j: hole-type
 #pragma unroll
-                for (int s = 0; s < kScales; s++) {
-                    unsigned m = ((e >> s) & 1u) | (((ne >> s) & 1u) << 1) | (((n >> s) & 1u) << 2) | (((nw >> s) & 1u) << 3) |
-                                 (((w >> s) & 1u) << 4) | (((sw >> s) & 1u) << 5) | (((so >> s) & 1u) << 6) | (((se >> s) & 1u) << 7);
-                    unsigned fg = (c >> s) & 1u;
-                    out[s] |= m << (8 * j);
-                    // outer-type: foreground, W/NW/N/NE background, not isolated
-                    // hole-type : background, W and N foreground
-                    bool outer = fg && m != 0 && (m & 0x1Eu) == 0;
-                    bool hole = !fg && (m & 0x14u) == 0x14u;
-                    if (outer || hole) {
-                        unsigned k = atomicAdd(&sNStart, 1u);
-                        unsigned ent = (unsigned)gx | ((unsigned)gy << 12) | ((unsigned)s << 24) | ((hole ? 1u : 0u) << 26);
-                        if (k < (unsigned)kBlockStarts) {
-                            sStart[k] = ent;
-                        } else {                                  // pathological tile (> 1024 candidates): go to the list directly
-                            unsigned kk = atomicAdd(&n_starts[b], 1u);
-                            if (kk < cfg.cap_starts) starts[(size_t)b * cfg.cap_starts + kk] = ent;
-                            else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
-                        }
-                    }
+        for (int s = 0; s < kScales; s++) {
+            unsigned six[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const int by = ty + r;
+                unsigned v = (unsigned)(sRow[s][by] >> tx4) & 63u;                       // ring bits tx4 .. tx4 + 5
+                if (tx4 == TW - 4) v |= ((unsigned)(sRing[s][0] >> by) & 1u) << 4 | ((unsigned)(sRing[s][1] >> by) & 1u) << 5;
+                six[r] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int gx = x0 + tx4 + j;
+                if (gx < cols && gy < rows) {
+                    const unsigned idx = ((six[0] >> j) & 7u) | (((six[1] >> j) & 7u) << 3) | (((six[2] >> j) & 7u) << 6);
+                    const unsigned t = sLut[idx];
+                    out[s] |= (t & 0xFFu) << (8 * j);
+                    cand |= ((t >> 8) & 1u) << (4 * s + j) | ((t >> 9) & 1u) << (16 + 4 * s + j);
+                }
+            }
+        }
+        if (cand) {                                                 // one reservation for all start candidates of these four pixels
+            const unsigned both = (cand | (cand >> 16)) & 0xFFFFu;
+            unsigned k = atomicAdd(&sNStart, (unsigned)__popc(both));
+            for (unsigned rest = both; rest; rest &= rest - 1u, k++) {
+                const int bit = __ffs((int)rest) - 1, s = bit >> 2, j = bit & 3;
+                const unsigned ent = (unsigned)(x0 + tx4 + j) | ((unsigned)gy << 12) | ((unsigned)s << 24) | (((cand >> (16 + bit)) & 1u) << 26);
+                if (k < (unsigned)kBlockStarts) {
+                    sStart[k] = ent;
+                } else {                                            // pathological tile (> 1024 candidates): go to the list directly
+                    const unsigned kk = atomicAdd(&n_starts[b], 1u);
+                    if (kk < cfg.cap_starts) starts[(size_t)b * cfg.cap_starts + kk] = ent;
+                    else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
                 }
             }
         }
@@ -214,6 +281,7 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         }
     }
     __syncthreads();
+    THR_STAMP(4);
     const unsigned ns = min(sNStart, (unsigned)kBlockStarts);
     if (tid == 0 && ns > 0) sBase = atomicAdd(&n_starts[b], ns);
     __syncthreads();
@@ -222,6 +290,10 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         if (k < cfg.cap_starts) starts[(size_t)b * cfg.cap_starts + k] = sStart[i];
         else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
     }
+#ifdef ASLAM_THR_STAMPS
+    THR_STAMP(5);
+    if (tid == 0 && blockIdx.x == 4000) printf("thr tile: load %lld integral %lld threshold %lld masks %lld flush %lld\n", tst[1] - tst[0], tst[2] - tst[1], tst[3] - tst[2], tst[4] - tst[3], tst[5] - tst[4]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
