@@ -13,10 +13,13 @@
 //     Y_K = Lambda Y_0      X_K = X_0 Gamma      Z_K = Z_0 - X_0 Psi Y_0      mu_R,K = mu_R,0 + X_0 psi
 //     Lambda+ = D Lambda - W G B       Gamma+ = Gamma D^T - A G V       Psi+ = Psi + A G B      psi+ = psi + A g
 //     with  B = H_S D Lambda  (3m x s),   A = Gamma D^T H_S^T  (s x 3m).
-// This is the reference's arithmetic regrouped (no symmetry of Sigma is assumed, nothing is approximated): the same identity
-// that fuses one frame's M corrections (ekf.hip) applied across frames.  Three kernels per window:
+// This is the reference's arithmetic regrouped: the same identity that fuses one frame's M corrections (ekf.hip) applied across
+// frames.  Nothing is approximated; the one property used beyond the identity is that the S x S block P is symmetric to
+// rounding (it is in the reference: aruco_slam.cpp:73, 204 keep Sigma = Sigma^T up to the last bit or two), so that inside the
+// chain kernel V = H_S P' is read as W^T and the innovation matrix A = H_S W + R is treated as symmetric.  X / Gamma and
+// Y / Lambda are NOT assumed to be transposes of each other.  Three kernels per window:
 //   k_ekf_win_chain   one workgroup runs the K frames on P and mu_S held in LDS (predict, records, innovation matrix,
-//                     block Gauss-Jordan, P update on the f64 matrix cores) and logs G, W, V, g, H3 and the Jacobians of every
+//                     block Gauss-Jordan, P update on the f64 matrix cores) and logs G, W, g, H3 and the Jacobians of every
 //                     frame; further workgroups copy X_0 (columns S of Sigma) and Y_0 (rows S) aside meanwhile;
 //   k_ekf_win_scan    4 x 4 workgroups replay the log: workgroup (i, j) carries 16 columns of Lambda, 16 rows of Gamma and
 //                     the 16 x 16 block of Psi they determine (columns of Lambda and rows of Gamma evolve independently);
@@ -31,7 +34,7 @@ namespace aslam {
 
 constexpr int WS = 66;                        // row stride (doubles) of a 64 x 64 image: conflict-free MFMA A-operand reads from LDS
 constexpr int WIMG = 64 * WS;                 // doubles per image
-constexpr int WLOG_G = 0, WLOG_W = WIMG, WLOG_V = 2 * WIMG, WLOG_g = 3 * WIMG, WLOG_H3 = WLOG_g + 64, WLOG_HREC = WLOG_H3 + 16;
+constexpr int WLOG_G = 0, WLOG_W = WIMG, WLOG_g = 2 * WIMG, WLOG_H3 = WLOG_g + 64, WLOG_HREC = WLOG_H3 + 16;
 constexpr int WLOG_STRIDE = WLOG_HREC + kWinM * 18;     // doubles per logged frame
 constexpr int WSM_LAM = 0, WSM_GAM = WIMG, WSM_PSI = 2 * WIMG, WSM_P = 3 * WIMG, WSM_psi = 4 * WIMG;    // layout of d_win_small
 constexpr int WCT = 512;                      // threads of the chain workgroup
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                                                       const unsigned char* __restrict__ obs_idx) {
     __shared__ __align__(16) double sP[WIMG];
     __shared__ __align__(16) double sW[WIMG];
-    __shared__ __align__(16) double sV[WIMG];          // V, later J = G V
+    __shared__ __align__(16) double sV[WIMG];          // J = G V
     __shared__ __align__(16) double sG[WIMG];
     __shared__ double sMu[64], sZe[64], sNu[64];
     __shared__ double sHr[kWinM][9], sHl[kWinM][9], sRd[kWinM][3];
@@ -257,26 +260,6 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                     sW[(3 * i + r) * WS + 3 * a + c] = (Pa[r * 3] * Hr[c * 3] + Pa[r * 3 + 1] * Hr[c * 3 + 1] + Pa[r * 3 + 2] * Hr[c * 3 + 2]) +
                                                        (Pb[r * 3] * Hl[c * 3] + Pb[r * 3 + 1] * Hl[c * 3 + 1] + Pb[r * 3 + 2] * Hl[c * 3 + 2]);
         }
-        // V = H P' (3m x s) into its image (block (a, i): correction a, block column i of S)
-        if (tid < (m + 1) * m) {
-            const int i = tid / m, a = tid - i * m;
-            double Pc[9], Pd[9];
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    Pc[r * 3 + c] = sP[r * WS + 3 * i + c];                      // P[0, i]
-                    Pd[r * 3 + c] = sP[(3 + 3 * a + r) * WS + 3 * i + c];        // P[1 + a, i]
-                }
-            const double* Hr = sHr[a];
-            const double* Hl = sHl[a];
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                    sV[(3 * a + r) * WS + 3 * i + c] = (Hr[r * 3] * Pc[c] + Hr[r * 3 + 1] * Pc[3 + c] + Hr[r * 3 + 2] * Pc[6 + c]) +
-                                                       (Hl[r * 3] * Pd[c] + Hl[r * 3 + 1] * Pd[3 + c] + Hl[r * 3 + 2] * Pd[6 + c]);
-        }
         ASLAM_LDS_BARRIER();
         WIN_STAMP(3);
         // ---- 4. innovation matrix A = H W + R (aruco_slam.cpp:146): thread (bi, bj) forms its 3x3 block into the G image ----
@@ -316,6 +299,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
         //    the rows and Y~ of pivot j + 1 it still holds in registers (lane = column; uniform values by v_readlane, no LDS),
         //    inverts S and hands Y~ and the corrected rows to the workers.  One barrier per step.
         const int tr = wave >> 1, tc0 = 2 * (wave & 1);           // tile ownership of the two products below (all eight waves)
+        const int kd = (n3 + 3) & ~3;                               // their depth: 3m, whole MFMA steps (rows / columns >= 3m of G, J are zero)
         const int gw = wave & 3;                                    // tile row of the working waves
         const int grow = 16 * gw + li;                              // this lane's operand row
         double nu = (wave == 4 && lane < n3) ? sZe[lane] : 0.0;     // wave 4: innovation / pseudo-innovation of row `lane`
@@ -393,23 +377,17 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
             }
         } else if (wave == 4) sNu[lane] = nu;
         ASLAM_LDS_BARRIER();
-        WIN_STAMP(6);
-        // ---- 5. log V before J replaces it (16-byte stores; nothing in the frame loop waits for global stores: the barriers
-        //         order LDS traffic only) ----
-        for (int e = tid; e < WIMG / 2; e += WCT) reinterpret_cast<double2*>(log + WLOG_V)[e] = reinterpret_cast<const double2*>(sV)[e];
-        ASLAM_LDS_BARRIER();
-        WIN_STAMP(7);
-        // ---- 6. J = G V on the f64 matrix cores, same tile ownership; column 63 of V (padding, s <= 63) is nu, so column 63 of J is g ----
+        // ---- 5. J = G V on the f64 matrix cores, same tile ownership.  V = H P' is W^T (P' is symmetric to rounding, like A above),
+        //         so the B operand is read from W's image transposed; column 63 (padding, s <= 63) is nu, so column 63 of J is g ----
         {
             v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
             const bool gcol = 16 * tc0 + 16 + li == 63;
-            for (int p0 = 0; p0 < 64; p0 += 4) {
+            for (int p0 = 0; p0 < kd; p0 += 4) {
                 const double a = sG[gpix(16 * tr + li, p0 + lk)];
-                const double b0 = sV[(p0 + lk) * WS + 16 * tc0 + li], b1 = gcol ? sNu[p0 + lk] : sV[(p0 + lk) * WS + 16 * tc0 + 16 + li];
+                const double b0 = sW[(16 * tc0 + li) * WS + p0 + lk], b1 = gcol ? sNu[p0 + lk] : sW[(16 * tc0 + 16 + li) * WS + p0 + lk];
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
             }
-            ASLAM_LDS_BARRIER();                                        // every wave has read V
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 sV[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li] = acc0[reg];
@@ -427,7 +405,7 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
                 acc0[reg] = sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li];
                 acc1[reg] = sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + 16 + li];
             }
-            for (int p0 = 0; p0 < 64; p0 += 4) {
+            for (int p0 = 0; p0 < kd; p0 += 4) {
                 const double a = -sW[(16 * tr + li) * WS + p0 + lk];
                 const double b0 = sV[(p0 + lk) * WS + 16 * tc0 + li], b1 = sV[(p0 + lk) * WS + 16 * tc0 + 16 + li];
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
@@ -443,7 +421,6 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
         if (tid < 64) {                                             // column 63 of the product is -(W g): mu_S += W g (aruco_slam.cpp:203)
             sMu[tid] -= sP[tid * WS + 63];
             sP[tid * WS + 63] = 0.0;
-            sV[tid * WS + 63] = 0.0;
         }
         WIN_STAMP(9);
         // log G and W (both stay untouched until the next frame's steps 3 / 4, behind a barrier)
@@ -462,9 +439,9 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
     if (tid == 0 && wd.K > 3) {
         if (false) printf("gj step: loads+S %lld inv %lld frags+mfma %lld writeback %lld copy %lld barrier %lld | step %lld\n", gst[1] - gst[0], gst[2] - gst[1], gst[3] - gst[2],
                gst[4] - gst[3], gst[5] - gst[4], gst[6] - gst[5], gst[6] - gst[0]);
-        printf("chain m=%d cycles: predict %lld records %lld barrier+prefetch %lld WV %lld A %lld GJ %lld G,g %lld logV %lld J %lld P,mu %lld logGW %lld | frame %lld\n", m,
+        printf("chain m=%d cycles: predict %lld records %lld barrier+prefetch %lld WV %lld A %lld GJ %lld G,nu+J %lld P,mu %lld logGW %lld | frame %lld\n", m,
                stamps[1] - stamps[0], stamps[2] - stamps[1], 0LL, stamps[3] - stamps[2], stamps[4] - stamps[3], stamps[5] - stamps[4],
-               stamps[6] - stamps[5], stamps[7] - stamps[6], stamps[8] - stamps[7], stamps[9] - stamps[8], stamps[10] - stamps[9], stamps[10] - stamps[0]);
+               stamps[8] - stamps[5], stamps[9] - stamps[8], stamps[10] - stamps[9], stamps[10] - stamps[0]);
     }
 #endif
     // ---- the window's result on S: P_K for the flush, mu_S in place; bookkeeping of the last frame ----
@@ -476,12 +453,12 @@ __global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Replay of the log: workgroup (x = j, y = i) carries Lambda[:, 16j .. 16j+15], Gamma[16i .. 16i+15, :], Psi block (i, j).
-// The next frame's record (G, W, V images: 100 KB) is fetched into registers while the current one is multiplied.
+// The next frame's record (G, W images: 68 KB) is fetched into registers while the current one is multiplied.
 constexpr int WPF = (WLOG_STRIDE / 2 + 255) / 256;   // 16-byte loads per thread and frame (26): the whole record, unconditionally
 constexpr int WREC = WPF * 256 * 2;                  // doubles staged per frame (a little past the record: the log has slack)
 
 __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
-    __shared__ __align__(16) double sRec[WREC];          // one logged frame: G | W | V | g | H3 | Jacobians
+    __shared__ __align__(16) double sRec[WREC];          // one logged frame: G | W | g | H3 | Jacobians
     __shared__ double sLam[64][17];            // Lambda columns (s x 16)
     __shared__ double sGam[16][WS];            // Gamma rows (16 x s)
     __shared__ double sB[64][17], sGB[64][17]; // B = H D Lambda (3m x 16), G B
@@ -489,7 +466,6 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
     __shared__ double sPsi[16][17], spsi[16];
     const double* sG = sRec + WLOG_G;
     const double* sW = sRec + WLOG_W;
-    const double* sV = sRec + WLOG_V;
     const double* sgv = sRec + WLOG_g;
     const double* sH3 = sRec + WLOG_H3;
     const double (*sHrec)[18] = reinterpret_cast<const double (*)[18]>(sRec + WLOG_HREC);
@@ -569,7 +545,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
             for (int reg = 0; reg < 4; reg++) { sGB[16 * wave + lk + 4 * reg][li] = accB[reg]; sAG[lk + 4 * reg][16 * wave + li] = accA[reg]; }
         }
         ASLAM_LDS_BARRIER();
-        // Lambda -= W GB (wave w: tile row w), Gamma -= AG V (wave w: tile column w), Psi += A GB (depth split over the waves)
+        // Lambda -= W GB (wave w: tile row w), Gamma -= AG V = AG W^T (wave w: tile column w), Psi += A GB (depth split over the waves)
         {
             v4d accL, accG, accP = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -577,7 +553,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
             for (int p0 = 0; p0 < 64; p0 += 4) {
                 const double a1 = -sW[(16 * wave + li) * WS + p0 + lk], b1 = sGB[p0 + lk][li];
                 accL = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accL, 0, 0, 0);
-                const double a2 = -sAG[li][p0 + lk], b2 = sV[(p0 + lk) * WS + 16 * wave + li];
+                const double a2 = -sAG[li][p0 + lk], b2 = sW[(16 * wave + li) * WS + p0 + lk];      // V = W^T
                 accG = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accG, 0, 0, 0);
             }
             for (int p0 = 16 * wave; p0 < 16 * wave + 16; p0 += 4) {
