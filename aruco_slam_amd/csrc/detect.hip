@@ -933,38 +933,51 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
         const uint8_t* gimg = gray + (size_t)wk.frame * rows * cols;
 
         for (int i = lane; i < 256; i += 64) hist[i] = 0;
-        if (lane == 0) {
-            // cv::getPerspectiveTransform(corners -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)); elimination with partial pivoting
-            const float dstx[4] = {0.f, (float)S - 1, (float)S - 1, 0.f};
-            const float dsty[4] = {0.f, 0.f, (float)S - 1, (float)S - 1};
-            for (int i = 0; i < 4; i++) {
-                float sx = fc->c[2 * i], sy = fc->c[2 * i + 1];
-                sA[i][0] = sA[i + 4][3] = sx;
-                sA[i][1] = sA[i + 4][4] = sy;
-                sA[i][2] = sA[i + 4][5] = 1;
-                sA[i][3] = sA[i][4] = sA[i][5] = sA[i + 4][0] = sA[i + 4][1] = sA[i + 4][2] = 0;
-                sA[i][6] = -(double)sx * dstx[i];
-                sA[i][7] = -(double)sy * dstx[i];
-                sA[i + 4][6] = -(double)sx * dsty[i];
-                sA[i + 4][7] = -(double)sy * dsty[i];
-                sB[i] = dstx[i];
-                sB[i + 4] = dsty[i];
+        {
+            // cv::getPerspectiveTransform(corners -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)): the 8 x 8 elimination with partial pivoting, one
+            // matrix element per lane (row er = lane / 8, column ec = lane % 8; every lane of a row carries the row's right-hand side).
+            // Every element goes through exactly the operations of the sequential elimination (quotient, product, difference; first
+            // maximal pivot), so the result is bit-identical to it - only the 58 k cycles of dependent LDS traffic on one lane are gone.
+            const int er = lane >> 3, ec = lane & 7, ei = er & 3;
+            const float dstx = (ei == 1 || ei == 2) ? (float)S - 1 : 0.f;
+            const float dsty = ei >= 2 ? (float)S - 1 : 0.f;
+            const float sx = fc->c[2 * ei], sy = fc->c[2 * ei + 1];
+            const float dst = er < 4 ? dstx : dsty;
+            double ea;
+            if (ec == 6) ea = -(double)sx * dst;
+            else if (ec == 7) ea = -(double)sy * dst;
+            else {
+                const int k = er < 4 ? ec : ec - 3;                  // rows 0..3: (sx, sy, 1) in columns 0..2; rows 4..7: in columns 3..5
+                ea = k == 0 ? (double)sx : k == 1 ? (double)sy : k == 2 ? 1.0 : 0.0;
             }
+            double eb = dst;
             for (int col = 0; col < 8; col++) {
                 int piv = col;
-                double best = fabs(sA[col][col]);
-                for (int r = col + 1; r < 8; r++)
-                    if (fabs(sA[r][col]) > best) { best = fabs(sA[r][col]); piv = r; }
-                if (piv != col) {
-                    for (int c = 0; c < 8; c++) { double t = sA[piv][c]; sA[piv][c] = sA[col][c]; sA[col][c] = t; }
-                    double t = sB[piv]; sB[piv] = sB[col]; sB[col] = t;
-                }
+                double best = fabs(__shfl(ea, col * 8 + col));
                 for (int r = col + 1; r < 8; r++) {
-                    double fct = sA[r][col] / sA[col][col];
-                    for (int c = col; c < 8; c++) sA[r][c] -= fct * sA[col][c];
-                    sB[r] -= fct * sB[col];
+                    const double v = fabs(__shfl(ea, r * 8 + col));
+                    if (v > best) { best = v; piv = r; }
+                }
+                if (piv != col) {                                    // uniform
+                    const double fromPiv = __shfl(ea, piv * 8 + ec), fromCol = __shfl(ea, col * 8 + ec);
+                    const double bPiv = __shfl(eb, piv * 8), bCol = __shfl(eb, col * 8);
+                    if (er == col) { ea = fromPiv; eb = bPiv; }
+                    else if (er == piv) { ea = fromCol; eb = bCol; }
+                }
+                const double pv = __shfl(ea, col * 8 + col);
+                const double mine = __shfl(ea, er * 8 + col);
+                const double rowc = __shfl(ea, col * 8 + ec), brow = __shfl(eb, col * 8);
+                if (er > col) {
+                    const double fct = mine / pv;
+                    if (ec >= col) ea -= fct * rowc;
+                    eb -= fct * brow;
                 }
             }
+            sA[er][ec] = ea;
+            if (ec == 0) sB[er] = eb;
+        }
+        __syncthreads();
+        if (lane == 0) {
             double x[8];
             for (int i = 7; i >= 0; i--) {
                 double s = sB[i];
