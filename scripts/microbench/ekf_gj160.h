@@ -100,12 +100,10 @@ __device__ __forceinline__ void gj160_sweep(double* __restrict__ G, int n3, int 
         }
     }
     v4d ga[GJ160_TPW];
+    int rowk[GJ160_TPW], colk[GJ160_TPW];                          // this lane's operand row / column of every tile (unused slots: tile (0, 0))
+#pragma unroll
+    for (int k = 0; k < GJ160_TPW; k++) { rowk[k] = 16 * max(tl.tr[k], 0) + li; colk[k] = 16 * max(tl.tc[k], 0) + li; }
     double nu[3] = {0.0, 0.0, 0.0}, ze[3] = {0.0, 0.0, 0.0};
-    double Rp[3][3], Yp[3][3];                                      // prepare wave: rows and Y~ of the pivot prepared last, [k][slot]
-#pragma unroll
-    for (int k = 0; k < 3; k++)
-#pragma unroll
-        for (int s = 0; s < 3; s++) { Rp[k][s] = 0.0; Yp[k][s] = 0.0; }
     if (wave < 4) {
 #pragma unroll
         for (int k = 0; k < GJ160_TPW; k++) {
@@ -142,7 +140,17 @@ __device__ __forceinline__ void gj160_sweep(double* __restrict__ G, int n3, int 
                         R[q][s] = (s < 2 || lane < GJ160_N - 128) ? sPub[(jb * 32 + srow) * GJ160_SW + lane + 64 * s] : 0.0;
                     }
                 if (j >= 0) {
-                    // step j's correction of these rows: C~_j[p + q][k] = R_j[k][p + q] (rows behind pivot j), Y~_j from the registers
+                    // step j's correction of these rows: C~_j[p + q][k] = R_j[k][p + q] (rows behind pivot j); R_j and Y~_j are what this
+                    // wave handed over one phase ago (read back from LDS: keeping them in registers would cost every wave 36 VGPRs)
+                    double Rp[3][3], Yp[3][3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+#pragma unroll
+                        for (int s = 0; s < 3; s++) {
+                            const bool in = s < 2 || lane < GJ160_N - 128;
+                            Rp[k][s] = in ? sRow[((jb ^ 1) * 4 + k) * GJ160_GW + lane + 64 * s] : 0.0;
+                            Yp[k][s] = in ? sGY[((jb ^ 1) * 4 + k) * GJ160_GW + lane + 64 * s] : 0.0;
+                        }
 #pragma unroll
                     for (int q = 0; q < 3; q++) {
                         const double c0 = gj160_pick(Rp[0], p + q), c1 = gj160_pick(Rp[1], p + q), c2 = gj160_pick(Rp[2], p + q);
@@ -160,15 +168,14 @@ __device__ __forceinline__ void gj160_sweep(double* __restrict__ G, int n3, int 
                 for (int s = 0; s < 3; s++) {
                     const int c = lane + 64 * s;
                     const double r0 = R[0][s] + (c == p ? 1.0 : 0.0), r1 = R[1][s] + (c == p + 1 ? 1.0 : 0.0), r2 = R[2][s] + (c == p + 2 ? 1.0 : 0.0);   // R~
-                    Yp[0][s] = fma(Si[2], r2, fma(Si[1], r1, Si[0] * r0));
-                    Yp[1][s] = fma(Si[5], r2, fma(Si[4], r1, Si[3] * r0));
-                    Yp[2][s] = fma(Si[8], r2, fma(Si[7], r1, Si[6] * r0));
+                    double Yn[3];
+                    Yn[0] = fma(Si[2], r2, fma(Si[1], r1, Si[0] * r0));
+                    Yn[1] = fma(Si[5], r2, fma(Si[4], r1, Si[3] * r0));
+                    Yn[2] = fma(Si[8], r2, fma(Si[7], r1, Si[6] * r0));
                     if (c < GJ160_N) {
 #pragma unroll
-                        for (int k = 0; k < 3; k++) { sGY[(jb * 4 + k) * GJ160_GW + c] = Yp[k][s]; sRow[(jb * 4 + k) * GJ160_GW + c] = R[k][s]; }
+                        for (int k = 0; k < 3; k++) { sGY[(jb * 4 + k) * GJ160_GW + c] = Yn[k]; sRow[(jb * 4 + k) * GJ160_GW + c] = R[k][s]; }
                     }
-#pragma unroll
-                    for (int k = 0; k < 3; k++) Rp[k][s] = R[k][s];
                 }
                 // nu_r += (C_r S^-1) ze_p for the rows behind the pivot: C[r][k] = R[k][r] there, u = S^-1 ze_p
                 const double z0 = gj160_pick(ze, p), z1 = gj160_pick(ze, p + 1), z2 = gj160_pick(ze, p + 2);
@@ -186,13 +193,14 @@ __device__ __forceinline__ void gj160_sweep(double* __restrict__ G, int n3, int 
             // (no branch per tile: an unused slot multiplies tile (0, 0)'s operands into an accumulator nobody reads, and the
             // operand loads of all tiles are in flight before the first product is issued)
             double af[GJ160_TPW], bf[GJ160_TPW];
+            const double* rowbase = sRow + (cb * 4 + lk) * GJ160_GW;
+            const double* ybase = sGY + (cb * 4 + lk) * GJ160_GW;
 #pragma unroll
             for (int k = 0; k < GJ160_TPW; k++) {
-                const int row = 16 * max(tl.tr[k], 0) + li;
-                const double rr = sRow[(cb * 4 + lk) * GJ160_GW + row];
-                af[k] = row < p0 ? rr : -rr;
-                if (lk < 3 && row == p0 + lk) af[k] += 1.0;
-                bf[k] = sGY[(cb * 4 + lk) * GJ160_GW + 16 * max(tl.tc[k], 0) + li];
+                const double rr = rowbase[rowk[k]];
+                af[k] = rowk[k] < p0 ? rr : -rr;
+                if (lk < 3 && rowk[k] == p0 + lk) af[k] += 1.0;
+                bf[k] = ybase[colk[k]];
             }
 #pragma unroll
             for (int k = 0; k < GJ160_TPW; k++) ga[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[k], bf[k], ga[k], 0, 0, 0);
