@@ -32,17 +32,19 @@ constexpr int LW = TW + 2 * HALO;   // 88
 constexpr int LH = TH + 2 * HALO;   // 56
 constexpr int kBlockStarts = 1024;  // start candidates staged per tile before one reservation in the frame's list
 
-template <int R> __device__ __forceinline__ unsigned box_mean(const unsigned (*I)[LW + 1], int ly, int lx) {
-    constexpr unsigned k2 = (2 * R + 1) * (2 * R + 1);
-    unsigned sum = I[ly + R + 1][lx + R + 1] - I[ly - R][lx + R + 1] - I[ly + R + 1][lx - R] + I[ly - R][lx - R];
-    return (2u * sum + k2) / (2u * k2);       // round-to-nearest; k2 is odd so a tie cannot occur (division by a constant)
+// adaptiveThreshold(MEAN_C, BINARY_INV): foreground iff  v - mean <= -C  with  mean = round(sum / k^2) = floor((2 sum + k^2) / (2 k^2))
+// (k^2 odd: no tie).  For integers  floor(a / b) >= t  <=>  a >= b t  (b > 0), so the decision needs no division:
+//     mean >= v + C   <=>   2 sum + k^2 >= 2 k^2 (v + C)   <=>   2 sum >= k^2 (2 (v + C) - 1).
+template <int R> __device__ __forceinline__ bool box_is_fg(const unsigned (*I)[LW + 1], int ly, int lx, int v_plus_c) {
+    constexpr int k2 = (2 * R + 1) * (2 * R + 1);
+    const int sum = (int)(I[ly + R + 1][lx + R + 1] - I[ly - R][lx + R + 1] - I[ly + R + 1][lx - R] + I[ly - R][lx - R]);
+    return 2 * sum >= k2 * (2 * v_plus_c - 1);
 }
-
-// runtime window radius (DetectorParameters other than the default 3 / 13 / 23): the same exact rounding, division by a variable
-__device__ __forceinline__ unsigned box_mean_r(const unsigned (*I)[LW + 1], int ly, int lx, int R) {
-    const unsigned k2 = (unsigned)((2 * R + 1) * (2 * R + 1));
-    const unsigned sum = I[ly + R + 1][lx + R + 1] - I[ly - R][lx + R + 1] - I[ly + R + 1][lx - R] + I[ly - R][lx - R];
-    return (2u * sum + k2) / (2u * k2);
+// runtime window radius (DetectorParameters other than the default 3 / 13 / 23): the same exact test
+__device__ __forceinline__ bool box_is_fg_r(const unsigned (*I)[LW + 1], int ly, int lx, int R, int v_plus_c) {
+    const int k2 = (2 * R + 1) * (2 * R + 1);
+    const int sum = (int)(I[ly + R + 1][lx + R + 1] - I[ly - R][lx + R + 1] - I[ly + R + 1][lx - R] + I[ly - R][lx - R]);
+    return 2 * sum >= k2 * (2 * v_plus_c - 1);
 }
 
 #ifdef ASLAM_THR_STAMPS
@@ -181,15 +183,15 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         unsigned bits = 0;
         if (gx >= 0 && gx < cols && gy >= 0 && gy < rows) {
             const int lx = bx - 1 + HALO, ly = by - 1 + HALO;
-            const int v = g[ly][lx];
+            const int vc = (int)g[ly][lx] + cfg.thresh_c;
             if (kDefaultWindows) {
-                if (v - (int)box_mean<1>(I, ly, lx) <= -cfg.thresh_c) bits |= 1u;
-                if (v - (int)box_mean<6>(I, ly, lx) <= -cfg.thresh_c) bits |= 2u;
-                if (v - (int)box_mean<11>(I, ly, lx) <= -cfg.thresh_c) bits |= 4u;
+                if (box_is_fg<1>(I, ly, lx, vc)) bits |= 1u;
+                if (box_is_fg<6>(I, ly, lx, vc)) bits |= 2u;
+                if (box_is_fg<11>(I, ly, lx, vc)) bits |= 4u;
             } else {
 #pragma unroll
                 for (int s = 0; s < kScales; s++)
-                    if (s < cfg.n_scales && v - (int)box_mean_r(I, ly, lx, cfg.win_r[s]) <= -cfg.thresh_c) bits |= 1u << s;
+                    if (s < cfg.n_scales && box_is_fg_r(I, ly, lx, cfg.win_r[s], vc)) bits |= 1u << s;
             }
         }
         return bits;
