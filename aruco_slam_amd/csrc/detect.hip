@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
     CkptRec* ckdst = ckpt;
     unsigned ci_keep = 0;
     unsigned type = 0, sc = 0;
-    long long area = 0;
+    int area = 0;                       // twice the signed area (shoelace); |step term| <= 4095, <= 5120 steps: fits 32 bits
 
     for (;;) {
         // ---- refill idle lanes from the wave's private ticket range; a new range costs one atomic per kTraceChunk tickets ----
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                 if ((n & (kCkptStride - 1)) == 0) myck[n / kCkptStride] = (unsigned)w.x | ((unsigned)w.y << 12) | ((unsigned)w.s << 24);
                 const int px = w.x, py = w.y;
                 walk_step(w, m);
-                area += (long long)px * w.y - (long long)w.x * py;
+                area += px * (w.y - py) - (w.x - px) * py;         // = px * w.y - w.x * py, with unit steps in small integers
                 n++;
                 if (w.x == sx && w.y == sy && w.s == s0) {
                     // closed by the smallest surviving key on this border: emit it from the start the sequential scan would
