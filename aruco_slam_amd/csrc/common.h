@@ -113,7 +113,8 @@ struct SlamParams {
 // Neighbour-mask planes are stored in 8x8-pixel tiles (one 64-byte line per tile) so that a border walk, which moves one
 // pixel at a time in any direction, stays on the same cache line for several steps.  pitch is a multiple of 64.
 __host__ __device__ inline size_t nbr_index(int x, int y, int pitch) {
-    return ((size_t)(y >> 3) * (size_t)(pitch >> 3) + (size_t)(x >> 3)) * 64u + (size_t)((y & 7) << 3) + (size_t)(x & 7);
+    // 32-bit arithmetic: a plane is rows x pitch < 2^32 bytes (the border walks pay for every instruction of a step)
+    return (size_t)((((unsigned)(y >> 3) * (unsigned)(pitch >> 3) + (unsigned)(x >> 3)) << 6) + (unsigned)((y & 7) << 3) + (unsigned)(x & 7));
 }
 __host__ __device__ inline size_t nbr_plane_bytes(int rows, int pitch) { return (size_t)((rows + 7) & ~7) * (size_t)pitch; }
 

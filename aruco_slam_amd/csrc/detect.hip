@@ -538,7 +538,11 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
             continue;                                              // every candidate just picked up was discarded: fetch more
         }
 
-        // ---- one step per busy lane ----
+        // ---- one step per busy lane; when nothing can be picked up (every lane busy, queue drained, or this wave carries a long walk
+        //      and has used up its ticket range) the bookkeeping above cannot change anything: several steps per round - a border walk
+        //      is one dependent chain, and the launch lasts as long as its longest one: every instruction of a step counts ----
+        const int reps = (idle == 0ull || drained || (lo == hi && long_walk)) ? 16 : 1;   // wave-uniform
+        for (int rep = 0; rep < reps; rep++) {
         if (mode == 1) {
             const unsigned m = plane[nbr_index(w.x, w.y, pitch)];
             bool dead = false;
@@ -598,6 +602,8 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
         } else if (mode == 2) {
             ckdst[wi] = CkptRec{myck[wi], ci_keep};           // one checkpoint per iteration (at most cfg.ckpt_per_walk)
             if (++wi >= n) mode = 0;
+        }
+        if (reps > 1 && __ballot(mode != 0) == 0ull) break;
         }
     }
 #ifdef ASLAM_TRACE_TIMELINE
