@@ -451,7 +451,20 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                                               unsigned* __restrict__ n_points, CkptRec* __restrict__ ckpt,
                                               unsigned* __restrict__ n_ckpt, unsigned* __restrict__ lane_ckpt) {
     __shared__ unsigned sPre[kMaxFramesPerCall + 1], sPreB[kMaxFramesPerCall + 1];
+    // One border-following step as a table: (neighbour mask m, back direction s) -> dx + 1 | dy + 1 << 2 | new s << 4 | "this state is
+    // the start state of an outer-type candidate" << 7 | "... of a hole-type candidate" << 8.  A walk is one dependent chain and the
+    // launch lasts as long as its longest one, so the ~35 instructions of walk_step / first_outer / first_hole become one LDS read.
+    __shared__ unsigned short sStep[256 * 8];
     const int lane = threadIdx.x & 63;
+    for (int i = lane; i < 256 * 8; i += 64) {
+        const unsigned m = (unsigned)i >> 3;
+        const int sd = i & 7;
+        Walk t{0, 0, sd};
+        if (m != 0) walk_step(t, m);
+        const bool co = (m & 0x1Eu) == 0 && sd == first_outer(m);
+        const bool ch = (m & 3u) == 2u && sd == first_hole(m);
+        sStep[i] = (unsigned short)((unsigned)(t.x + 1) | ((unsigned)(t.y + 1) << 2) | ((unsigned)t.s << 4) | (co ? 0x80u : 0u) | (ch ? 0x100u : 0u));
+    }
     for (int i = lane; i <= nframes; i += 64) { sPre[i] = pre[i]; sPreB[i] = pre_big[i]; }
     __syncthreads();
     // tickets [0, totalB) are the "big" start candidates of all frames (long walks first), [totalB, total) the others
@@ -549,8 +562,8 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
             // Is this state the start state of a scan candidate (of either type)?  A smaller key that passes the run test
             // belongs to a walker that will do (or hand on) this border: stop.  Otherwise remember the smallest key per
             // type: whoever closes the border needs the first start of the border's own type (outer / hole).
-            const bool co = (m & 0x1Eu) == 0 && w.s == first_outer(m);
-            const bool ch = (m & 3u) == 2u && w.s == first_hole(m);
+            const unsigned st = sStep[(m << 3) | (unsigned)w.s];
+            const bool co = (st & 0x80u) != 0, ch = (st & 0x100u) != 0;
             if (co || ch) {
                 const int key = w.y * cols + w.x + (ch ? 1 : 0);
                 if (key < key0) dead = ch ? run_is_top_hole(plane, w.x + 1, w.y, pitch, cols) : run_is_top_outer(plane, w.x, w.y, pitch, m);
@@ -561,9 +574,9 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                 mode = 0;
             } else {
                 if ((n & (kCkptStride - 1)) == 0) myck[n / kCkptStride] = (unsigned)w.x | ((unsigned)w.y << 12) | ((unsigned)w.s << 24);
-                const int px = w.x, py = w.y;
-                walk_step(w, m);
-                area += px * (w.y - py) - (w.x - px) * py;         // = px * w.y - w.x * py, with unit steps in small integers
+                const int ddx = (int)(st & 3u) - 1, ddy = (int)((st >> 2) & 3u) - 1;
+                area += w.x * ddy - ddx * w.y;                     // = px * (py + dy) - (px + dx) * py, unit steps in small integers
+                w.x += ddx; w.y += ddy; w.s = (int)((st >> 4) & 7u);
                 n++;
                 if (w.x == sx && w.y == sy && w.s == s0) {
                     // closed by the smallest surviving key on this border: emit it from the start the sequential scan would
