@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                     const unsigned long long t = ~r;
                     len = t ? __ffsll((long long)t) - 1 : 64;
                 }
-                if (len >= kBigRun || e + len >= 64) bigm |= 1u << bit;
+                // (a background run is long almost everywhere: a hole counts as big only if its run is long AND closed inside the tile)
+                const bool holeb = ((cand >> (16 + bit)) & 1u) != 0;
+                if (holeb ? (len >= kBigRun && e + len < 64) : (len >= kBigRun || e + len >= 64)) bigm |= 1u << bit;
             }
             const unsigned cap_big = cfg.cap_starts / kBigShare, cap_small = cfg.cap_starts - cap_big;
             const unsigned smallm = both & ~bigm;
@@ -644,8 +646,8 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                     steps += tl[2] & 0xFFFFFFFFull; tickets += tl[3] & 0xFFFFFFFFull;
                     maxit = max(maxit, (unsigned)(tl[2] >> 32)); maxn = max(maxn, (unsigned)(tl[3] >> 32)); avgit += (double)(tl[2] >> 32);
                 }
-                printf("TL frames %d waves %u duration %.1f us | waves finishing per tenth of it: %u %u %u %u %u %u %u %u %u %u | lane-steps %llu tickets %llu | iterations avg %.0f max %u | longest walk %u steps\n",
-                       nframes, gridDim.x, (double)(tend - t0) / 100.0, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], hist[9], steps, tickets,
+                printf("TL big %u frames %d waves %u duration %.1f us | waves finishing per tenth of it: %u %u %u %u %u %u %u %u %u %u | lane-steps %llu tickets %llu | iterations avg %.0f max %u | longest walk %u steps\n",
+                       totalB, nframes, gridDim.x, (double)(tend - t0) / 100.0, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], hist[9], steps, tickets,
                        avgit / gridDim.x, maxit, maxn);
                 *cnt = 0;
             }
