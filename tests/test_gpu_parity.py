@@ -285,6 +285,42 @@ def test_alternating_detection_only_and_full_calls_share_slots_safely():
         assert all(np.array_equal(x, y) for x, y in zip(da, db))
 
 
+def test_windowed_and_per_frame_ekf_agree_on_the_full_pipeline():
+    """cfg2 frames through detection + pose + EKF twice: with the windowed EKF (ekf_window.hip: chain / scan / flush, host planner)
+    and with every frame on the per-frame chain (ASLAM_NO_WINDOWS) - the same arithmetic regrouped, equal to rounding; the windowed
+    run must really have formed windows"""
+    import os
+    cfg = synth.CONFIGS["cfg2"]
+    w = synth.PanelWorld(cfg)
+    n = 96
+    frs = [w.frame(i) for i in range(n)]
+    ctxs = []
+    for windows in (True, False):
+        if not windows:
+            os.environ["ASLAM_NO_WINDOWS"] = "1"
+        try:
+            c = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=n, max_landmarks=w.L + 8)
+        finally:
+            os.environ.pop("ASLAM_NO_WINDOWS", None)
+        c.set_camera(w.K, np.zeros(5))
+        synth.apply_detector(cfg, c)
+        for i, fr in enumerate(frs):
+            c.synth_render(i, cfg.rows, cfg.cols, w.K, fr.ids, fr.poses, noise_amp=2, seed=i, download=False)
+        c.stage_encoders([f.wl for f in frs], [f.wr for f in frs], [f.dt for f in frs])
+        c.profile_enable(True); c.profile_reset()
+        c.run_staged(0, n // 2, with_ekf=True)
+        c.run_staged(n // 2, n - n // 2, with_ekf=True)
+        c.sync()
+        ctxs.append(c)
+    a, b = ctxs
+    assert a.profile_get()["k_ekf_win_chain"][0] > 0 and b.profile_get()["k_ekf_win_chain"][0] == 0
+    mu_a, S_a = a.get_state(); mu_b, S_b = b.get_state()
+    assert mu_a.shape == mu_b.shape and mu_a.size > 3 + 3 * 20
+    assert np.allclose(mu_a, mu_b, rtol=1e-10, atol=1e-12) and np.abs(S_a - S_b).max() <= 1e-10 * np.abs(S_a).max()
+    sa, sb = a.get_slot_ekf_stats(0, n), b.get_slot_ekf_stats(0, n)
+    assert np.array_equal(sa, sb)                                # markers, augments, updates, stationary per frame
+
+
 def test_pipelined_map_gather_delivers_the_same_records():
     """MapGather.gather_pipelined (export enqueued behind the EKF chain, collective one call behind) == the blocking export"""
     import torch
