@@ -69,8 +69,6 @@ struct aslam_ctx {
     uint8_t* d_nbr = nullptr;
     unsigned* d_starts = nullptr;          // per frame: cap_starts entries
     unsigned* d_nstarts = nullptr;
-    unsigned* d_nstarts_big = nullptr;     // ... of the "big" class (the last cap_starts / 8 entries of a frame's list, filled from the end)
-    unsigned* d_pre_trace_big = nullptr;
     Counters* d_ctr = nullptr;
     ContourRec* d_contours = nullptr;      // per frame: cap_contours records
     unsigned* d_ncontours = nullptr;
@@ -310,7 +308,6 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
         const int nf = std::min(max_frames_per_call(), first + count - f0);
         HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, kCounterHeads * sizeof(unsigned), st));   // queue heads and work count; the overflow mask is sticky
         HIP_TRY(c, hipMemsetAsync(c->d_nstarts + f0, 0, sizeof(unsigned) * nf, st));
-        HIP_TRY(c, hipMemsetAsync(c->d_nstarts_big + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_ncontours + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_npoints + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_nckpt + f0, 0, sizeof(unsigned) * nf, st));
@@ -323,13 +320,12 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
         unsigned* points = c->d_points + (size_t)f0 * g.cap_points;
         prof_begin(c, P_THRESH, st);
         launch_threshold(st, in, c->channels, c->in_frame_bytes, (size_t)g.cols * c->channels, nf,
-                         alias_gray ? nullptr : c->d_gray + (size_t)f0 * frame_px, nbr, g, starts, c->d_nstarts + f0, c->d_nstarts_big + f0, c->d_ctr);
+                         alias_gray ? nullptr : c->d_gray + (size_t)f0 * frame_px, nbr, g, starts, c->d_nstarts + f0, c->d_ctr);
         prof_end(c);
         prof_begin(c, P_TRACE, st);
-        launch_prefix(st, nf, c->d_nstarts + f0, g.cap_starts - g.cap_starts / 8u, 1u, c->d_pre_trace);
-        launch_prefix(st, nf, c->d_nstarts_big + f0, g.cap_starts / 8u, 1u, c->d_pre_trace_big);
+        launch_prefix(st, nf, c->d_nstarts + f0, g.cap_starts, 1u, c->d_pre_trace);
         CkptRec* ckpt = c->d_ckpt + (size_t)f0 * g.cap_ckpt;
-        launch_trace(st, c->nwaves, nbr, g, nf, starts, c->d_pre_trace_big, c->d_pre_trace, c->d_ctr, contours, c->d_ncontours + f0,
+        launch_trace(st, c->nwaves, nbr, g, nf, starts, c->d_pre_trace, c->d_ctr, contours, c->d_ncontours + f0,
                      c->d_npoints + f0, ckpt, c->d_nckpt + f0, c->d_lane_ckpt);
         launch_prefix(st, nf, c->d_nckpt + f0, g.cap_ckpt, 1u, c->d_pre_write);
         launch_trace_write(st, std::max(64, c->nwaves / 4), nbr, g, nf, c->d_pre_write, c->d_ctr, contours, ckpt, points);
@@ -524,7 +520,6 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && dalloc(&c->d_nbr, (size_t)kScales * nbr_plane_bytes(init->max_rows, (int)pitch) * B) == hipSuccess;
     ok = ok && dalloc(&c->d_starts, (size_t)c->init.cap_starts_per_frame * B) == hipSuccess;
     ok = ok && dalloc(&c->d_nstarts, B) == hipSuccess;
-    ok = ok && dalloc(&c->d_nstarts_big, B) == hipSuccess;
     ok = ok && dalloc(&c->d_ctr, 1) == hipSuccess;
     ok = ok && dalloc(&c->d_contours, (size_t)c->init.cap_contours_per_frame * B) == hipSuccess;
     ok = ok && dalloc(&c->d_ncontours, B) == hipSuccess;
@@ -536,7 +531,6 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && dalloc(&c->d_refine_mask, 15 * 15) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_write, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_trace, (size_t)max_frames_per_call() + 1) == hipSuccess;
-    ok = ok && dalloc(&c->d_pre_trace_big, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_quads, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_cands, (size_t)kCandMax * B) == hipSuccess;
     ok = ok && dalloc(&c->d_ncand, B) == hipSuccess;
@@ -555,7 +549,6 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && hipMemcpy(c->d_dict, codes.data(), codes.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemset(c->d_ctr, 0, sizeof(Counters)) == hipSuccess;
     ok = ok && hipMemset(c->d_nstarts, 0, sizeof(unsigned) * B) == hipSuccess;
-    ok = ok && hipMemset(c->d_nstarts_big, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_ncontours, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_npoints, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_nmarkers, 0, sizeof(unsigned) * B) == hipSuccess;
@@ -588,7 +581,7 @@ void aslam_destroy(aslam_ctx* c) {
     hipFree(c->d_in); hipFree(c->d_gray); hipFree(c->d_nbr); hipFree(c->d_starts); hipFree(c->d_ctr);
     hipFree(c->d_refine_mask);
     hipFree(c->d_ckpt); hipFree(c->d_nckpt); hipFree(c->d_lane_ckpt); hipFree(c->d_pre_write);
-    hipFree(c->d_nstarts); hipFree(c->d_nstarts_big); hipFree(c->d_pre_trace_big); hipFree(c->d_ncontours); hipFree(c->d_npoints); hipFree(c->d_pre_trace); hipFree(c->d_pre_quads);
+    hipFree(c->d_nstarts); hipFree(c->d_ncontours); hipFree(c->d_npoints); hipFree(c->d_pre_trace); hipFree(c->d_pre_quads);
     hipFree(c->d_contours); hipFree(c->d_points); hipFree(c->d_cands); hipFree(c->d_ncand); hipFree(c->d_finals);
     hipFree(c->d_nfinal); hipFree(c->d_work); hipFree(c->d_dict); hipFree(c->d_markers); hipFree(c->d_nmarkers);
     hipFree(c->d_obs); hipFree(c->d_enc); hipFree(c->d_synth);

@@ -5,10 +5,10 @@
 namespace aslam {
 
 void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t frame_stride, size_t row_step, int nframes,
-                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, unsigned* n_starts_big, Counters* ctr);
+                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, Counters* ctr);
 void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre);
 void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
-                  const unsigned* pre_big, const unsigned* pre, Counters* ctr, ContourRec* contours, unsigned* n_contours,
+                  const unsigned* pre, Counters* ctr, ContourRec* contours, unsigned* n_contours,
                   unsigned* n_points, CkptRec* ckpt, unsigned* n_ckpt, unsigned* lane_ckpt);
 void launch_trace_write(hipStream_t st, int nblocks, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* pre,
                         Counters* ctr, const ContourRec* contours, const CkptRec* ckpt, unsigned* points);

@@ -31,13 +31,6 @@ constexpr int TW = 64, TH = 32, HALO = 12;
 constexpr int LW = TW + 2 * HALO;   // 88
 constexpr int LH = TH + 2 * HALO;   // 56
 constexpr int kBlockStarts = 1024;  // start candidates staged per tile before one reservation in the frame's list
-constexpr int kBlockBig = 128;      // ... of which the last kBlockBig slots stage the "big" ones
-// Border walks are sequential, and a launch cannot end before its longest walk does (a panel outline: thousands of steps).  Start
-// candidates that open a long horizontal run (>= kBigRun pixels, or up to the tile edge) - the top edge of something large - go
-// to a separate list that k_trace works off FIRST, so that the long walks run beside the bulk of the short ones instead of
-// after it.  The big list is the last cap_starts / kBigShare entries of a frame's list, filled from the end.
-constexpr int kBigRun = 24;
-constexpr unsigned kBigShare = 8;
 
 // adaptiveThreshold(MEAN_C, BINARY_INV): foreground iff  v - mean <= -C  with  mean = round(sum / k^2) = floor((2 sum + k^2) / (2 k^2))
 // (k^2 odd: no tie).  For integers  floor(a / b) >= t  <=>  a >= b t  (b > 0), so the decision needs no division:
@@ -64,14 +57,14 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                                                    size_t in_row_step, uint8_t* __restrict__ gray_out,
                                                    uint8_t* __restrict__ nbr, DetectCfg cfg,
                                                    unsigned* __restrict__ starts, unsigned* __restrict__ n_starts,
-                                                   unsigned* __restrict__ n_starts_big, Counters* ctr, int nframes) {
+                                                   Counters* ctr, int nframes) {
     __shared__ uint8_t g[LH][LW];
     __shared__ unsigned I[LH + 1][LW + 1];
     __shared__ unsigned long long sRow[kScales][TH + 2];     // threshold decisions of ring row by, columns x0 - 1 .. x0 + 62 (bit = column)
     __shared__ unsigned long long sRing[kScales][2];         // ... of columns x0 + 63 and x0 + 64 (bit = ring row)
     __shared__ unsigned short sLut[512];
     __shared__ unsigned sStart[kBlockStarts];      // x | y << 12 | scale << 24 | type << 26
-    __shared__ unsigned sNStart, sBase, sNBig, sBaseB;
+    __shared__ unsigned sNStart, sBase;
 
     const int tid = threadIdx.x;
     // XCD-aware tile order: consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Give every
@@ -89,7 +82,7 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
 #ifdef ASLAM_THR_STAMPS
     long long tst[8] = {0};
 #endif
-    if (tid == 0) { sNStart = 0; sNBig = 0; }
+    if (tid == 0) sNStart = 0;
     THR_STAMP(0);
 
     // 1. gray tile with replicated border (BORDER_REPLICATE of the box filter)
@@ -265,48 +258,18 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                 }
             }
         }
-        if (cand) {                                                 // one reservation per class for the start candidates of these four pixels
+        if (cand) {                                                 // one reservation for all start candidates of these four pixels
             const unsigned both = (cand | (cand >> 16)) & 0xFFFFu;
-            unsigned bigm = 0;
-            for (unsigned rest = both; rest; rest &= rest - 1u) {
-                const int bit = __ffs((int)rest) - 1, s = bit >> 2, j = bit & 3;
-                const int e = tx4 + j + 1;                          // the candidate's bit in its ring row
-                int len = 64;                                       // the tile's last column (e = 64): the run leaves the tile
-                if (e < 64) {
-                    const unsigned long long row = sRow[s][ty + 1];
-                    const unsigned long long r = ((cand >> (16 + bit)) & 1u) ? ~row >> e : row >> e;   // hole: the background run
-                    const unsigned long long t = ~r;
-                    len = t ? __ffsll((long long)t) - 1 : 64;
-                }
-                // (a background run is long almost everywhere: a hole counts as big only if its run is long AND closed inside the tile)
-                const bool holeb = ((cand >> (16 + bit)) & 1u) != 0;
-                if (holeb ? (len >= kBigRun && e + len < 64) : (len >= kBigRun || e + len >= 64)) bigm |= 1u << bit;
-            }
-            const unsigned cap_big = cfg.cap_starts / kBigShare, cap_small = cfg.cap_starts - cap_big;
-            const unsigned smallm = both & ~bigm;
-            unsigned kS = smallm ? atomicAdd(&sNStart, (unsigned)__popc(smallm)) : 0u;
-            unsigned kB = bigm ? atomicAdd(&sNBig, (unsigned)__popc(bigm)) : 0u;
-            for (unsigned rest = both; rest; rest &= rest - 1u) {
+            unsigned k = atomicAdd(&sNStart, (unsigned)__popc(both));
+            for (unsigned rest = both; rest; rest &= rest - 1u, k++) {
                 const int bit = __ffs((int)rest) - 1, s = bit >> 2, j = bit & 3;
                 const unsigned ent = (unsigned)(x0 + tx4 + j) | ((unsigned)gy << 12) | ((unsigned)s << 24) | (((cand >> (16 + bit)) & 1u) << 26);
-                if ((bigm >> bit) & 1u) {
-                    const unsigned k = kB++;
-                    if (k < (unsigned)kBlockBig) {
-                        sStart[kBlockStarts - 1 - k] = ent;
-                    } else {                                        // more than the tile stages: go to the list directly
-                        const unsigned kk = atomicAdd(&n_starts_big[b], 1u);
-                        if (kk < cap_big) starts[(size_t)b * cfg.cap_starts + cfg.cap_starts - 1u - kk] = ent;
-                        else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
-                    }
-                } else {
-                    const unsigned k = kS++;
-                    if (k < (unsigned)(kBlockStarts - kBlockBig)) {
-                        sStart[k] = ent;
-                    } else {                                        // pathological tile: go to the list directly
-                        const unsigned kk = atomicAdd(&n_starts[b], 1u);
-                        if (kk < cap_small) starts[(size_t)b * cfg.cap_starts + kk] = ent;
-                        else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
-                    }
+                if (k < (unsigned)kBlockStarts) {
+                    sStart[k] = ent;
+                } else {                                            // pathological tile (> 1024 candidates): go to the list directly
+                    const unsigned kk = atomicAdd(&n_starts[b], 1u);
+                    if (kk < cfg.cap_starts) starts[(size_t)b * cfg.cap_starts + kk] = ent;
+                    else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
                 }
             }
         }
@@ -321,24 +284,13 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
     }
     __syncthreads();
     THR_STAMP(4);
-    const unsigned ns = min(sNStart, (unsigned)(kBlockStarts - kBlockBig)), nb = min(sNBig, (unsigned)kBlockBig);
-    if (tid == 0) {
-        if (ns > 0) sBase = atomicAdd(&n_starts[b], ns);
-        if (nb > 0) sBaseB = atomicAdd(&n_starts_big[b], nb);
-    }
+    const unsigned ns = min(sNStart, (unsigned)kBlockStarts);
+    if (tid == 0 && ns > 0) sBase = atomicAdd(&n_starts[b], ns);
     __syncthreads();
-    {
-        const unsigned cap_big = cfg.cap_starts / kBigShare, cap_small = cfg.cap_starts - cap_big;
-        for (unsigned i = tid; i < ns; i += 256) {
-            const unsigned k = sBase + i;
-            if (k < cap_small) starts[(size_t)b * cfg.cap_starts + k] = sStart[i];
-            else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
-        }
-        for (unsigned i = tid; i < nb; i += 256) {
-            const unsigned k = sBaseB + i;
-            if (k < cap_big) starts[(size_t)b * cfg.cap_starts + cfg.cap_starts - 1u - k] = sStart[kBlockStarts - 1 - i];
-            else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
-        }
+    for (unsigned i = tid; i < ns; i += 256) {
+        unsigned k = sBase + i;
+        if (k < cfg.cap_starts) starts[(size_t)b * cfg.cap_starts + k] = sStart[i];
+        else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
     }
 #ifdef ASLAM_THR_STAMPS
     THR_STAMP(5);
@@ -447,12 +399,12 @@ __device__ __forceinline__ bool run_is_top_hole(const uint8_t* __restrict__ plan
 // refilled from the queue every iteration with ONE atomic per wave, so a wave never waits for its longest walk.
 // Tickets number the start candidates of the whole call; `pre` holds the per-frame prefix of their counts.
 __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, DetectCfg cfg, int nframes,
-                                              const unsigned* __restrict__ starts, const unsigned* __restrict__ pre_big,
+                                              const unsigned* __restrict__ starts,
                                               const unsigned* __restrict__ pre, Counters* ctr,
                                               ContourRec* __restrict__ contours, unsigned* __restrict__ n_contours,
                                               unsigned* __restrict__ n_points, CkptRec* __restrict__ ckpt,
                                               unsigned* __restrict__ n_ckpt, unsigned* __restrict__ lane_ckpt) {
-    __shared__ unsigned sPre[kMaxFramesPerCall + 1], sPreB[kMaxFramesPerCall + 1];
+    __shared__ unsigned sPre[kMaxFramesPerCall + 1];
     // One border-following step as a table: (neighbour mask m, back direction s) -> dx + 1 | dy + 1 << 2 | new s << 4 | "this state is
     // the start state of an outer-type candidate" << 7 | "... of a hole-type candidate" << 8.  A walk is one dependent chain and the
     // launch lasts as long as its longest one, so the ~35 instructions of walk_step / first_outer / first_hole become one LDS read.
@@ -467,10 +419,9 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
         const bool ch = (m & 3u) == 2u && sd == first_hole(m);
         sStep[i] = (unsigned short)((unsigned)(t.x + 1) | ((unsigned)(t.y + 1) << 2) | ((unsigned)t.s << 4) | (co ? 0x80u : 0u) | (ch ? 0x100u : 0u));
     }
-    for (int i = lane; i <= nframes; i += 64) { sPre[i] = pre[i]; sPreB[i] = pre_big[i]; }
+    for (int i = lane; i <= nframes; i += 64) sPre[i] = pre[i];
     __syncthreads();
-    // tickets [0, totalB) are the "big" start candidates of all frames (long walks first), [totalB, total) the others
-    const unsigned totalB = sPreB[nframes], total = totalB + sPre[nframes];
+    const unsigned total = sPre[nframes];
     const int pitch = cfg.pitch, cols = cfg.cols;
 
 #ifdef ASLAM_TRACE_TIMELINE
@@ -510,15 +461,8 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
             const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
             if (mode == 0 && rank < take) {
                 const unsigned ticket = lo + rank;
-                unsigned e;
-                if (ticket < totalB) {
-                    if (!(ticket >= sPreB[f] && ticket < sPreB[f + 1])) f = ticket_frame(sPreB, nframes, ticket);
-                    e = starts[(size_t)f * cfg.cap_starts + cfg.cap_starts - 1u - (ticket - sPreB[f])];
-                } else {
-                    const unsigned ts = ticket - totalB;
-                    if (!(ts >= sPre[f] && ts < sPre[f + 1])) f = ticket_frame(sPre, nframes, ts);
-                    e = starts[(size_t)f * cfg.cap_starts + (ts - sPre[f])];
-                }
+                if (!(ticket >= sPre[f] && ticket < sPre[f + 1])) f = ticket_frame(sPre, nframes, ticket);
+                const unsigned e = starts[(size_t)f * cfg.cap_starts + (ticket - sPre[f])];
                 int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
                 sc = (e >> 24) & 3u;
                 type = (e >> 26) & 1u;
@@ -646,8 +590,8 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
                     steps += tl[2] & 0xFFFFFFFFull; tickets += tl[3] & 0xFFFFFFFFull;
                     maxit = max(maxit, (unsigned)(tl[2] >> 32)); maxn = max(maxn, (unsigned)(tl[3] >> 32)); avgit += (double)(tl[2] >> 32);
                 }
-                printf("TL big %u frames %d waves %u duration %.1f us | waves finishing per tenth of it: %u %u %u %u %u %u %u %u %u %u | lane-steps %llu tickets %llu | iterations avg %.0f max %u | longest walk %u steps\n",
-                       totalB, nframes, gridDim.x, (double)(tend - t0) / 100.0, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], hist[9], steps, tickets,
+                printf("TL frames %d waves %u duration %.1f us | waves finishing per tenth of it: %u %u %u %u %u %u %u %u %u %u | lane-steps %llu tickets %llu | iterations avg %.0f max %u | longest walk %u steps\n",
+                       nframes, gridDim.x, (double)(tend - t0) / 100.0, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], hist[9], steps, tickets,
                        avgit / gridDim.x, maxit, maxn);
                 *cnt = 0;
             }
@@ -1245,24 +1189,23 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
 // host launchers
 // ------------------------------------------------------------------------------------------------
 void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t frame_stride, size_t row_step, int nframes,
-                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, unsigned* n_starts_big,
-                      Counters* ctr) {
+                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, Counters* ctr) {
     const unsigned total = (unsigned)((cfg.cols + TW - 1) / TW) * (unsigned)((cfg.rows + TH - 1) / TH) * (unsigned)nframes;
     const bool def = cfg.n_scales == 3 && cfg.win_r[0] == 1 && cfg.win_r[1] == 6 && cfg.win_r[2] == 11;
     if (def)
         hipLaunchKernelGGL(k_threshold<true>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg,
-                           starts, n_starts, n_starts_big, ctr, nframes);
+                           starts, n_starts, ctr, nframes);
     else
         hipLaunchKernelGGL(k_threshold<false>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg,
-                           starts, n_starts, n_starts_big, ctr, nframes);
+                           starts, n_starts, ctr, nframes);
 }
 void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre) {
     hipLaunchKernelGGL(k_prefix, dim3(1), dim3(256), 0, st, nframes, counts, cap, per_ticket, pre);
 }
 void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
-                  const unsigned* pre_big, const unsigned* pre, Counters* ctr, ContourRec* contours, unsigned* n_contours,
+                  const unsigned* pre, Counters* ctr, ContourRec* contours, unsigned* n_contours,
                   unsigned* n_points, CkptRec* ckpt, unsigned* n_ckpt, unsigned* lane_ckpt) {
-    hipLaunchKernelGGL(k_trace, dim3(nwaves), dim3(64), 0, st, nbr, cfg, nframes, starts, pre_big, pre, ctr, contours, n_contours,
+    hipLaunchKernelGGL(k_trace, dim3(nwaves), dim3(64), 0, st, nbr, cfg, nframes, starts, pre, ctr, contours, n_contours,
                        n_points, ckpt, n_ckpt, lane_ckpt);
 }
 void launch_trace_write(hipStream_t st, int nblocks, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* pre,
