@@ -106,6 +106,7 @@ struct aslam_ctx {
     // frames that fuse the same landmarks; the batch's EKF work is enqueued one call later (or at the next synchronisation),
     // behind the NEXT batch's detection, so that the detection stream never waits for the host
     bool win_enabled = true;
+    int win_piece = kWinChainFrames;      // frames per chain piece (ASLAM_WIN_PIECE, 1..kWinChainFrames: a test knob)
     struct Pending { bool active = false; int first = 0, count = 0, ev = 0; } pend;
     hipEvent_t ev_obs[2] = {nullptr, nullptr}, ev_idx = nullptr;
     hipStream_t stream_win = nullptr;     // scan / flush of the windows, beside the chain on stream_ekf
@@ -490,6 +491,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     c->sp.useful_distance_threshold = init->useful_distance_threshold;
 
     c->win_enabled = std::getenv("ASLAM_NO_WINDOWS") == nullptr;
+    if (const char* e = std::getenv("ASLAM_WIN_PIECE")) c->win_piece = std::min(kWinChainFrames, std::max(1, std::atoi(e)));
     const int B = c->max_batch;
     const size_t px = (size_t)init->max_rows * init->max_cols;
     const size_t pitch = ((size_t)init->max_cols + 63) / 64 * 64;
@@ -803,11 +805,12 @@ int finalize_pending(aslam_ctx* c) {
             // the replay of each piece's log (scan) and the run's single pass over Sigma (flush) go to a second stream, so
             // that only the last piece's scan and the flush are not hidden behind the chain.
             hipStream_t sa = c->stream_ekf, sb = c->stream_win;
-            for (int k0 = 0; k0 < o.wd.K; k0 += kWinChainFrames) {
+            int piece = 0;
+            for (int k0 = 0; k0 < o.wd.K; k0 += c->win_piece, piece++) {
                 WinDesc sub = o.wd;
                 sub.first_slot = o.wd.first_slot + k0;
-                sub.K = std::min(kWinChainFrames, o.wd.K - k0);
-                sub.cont = k0 > 0 ? 1 : 0;
+                sub.K = std::min(c->win_piece, o.wd.K - k0);
+                sub.cont = piece;                                  // index of the piece: the scan alternates between two accumulator sets
                 sub.log0 = k0;
                 prof_begin(c, P_EKF_WIN_CHAIN, sa);
                 launch_ekf_win_chain(sa, c->ekf, c->sp, sub, c->d_obs, c->d_nmarkers, c->d_enc, c->d_obs_idx + (size_t)sub.first_slot * kWinM);
@@ -820,7 +823,9 @@ int finalize_pending(aslam_ctx* c) {
                 prof_end(c);
             }
             prof_begin(c, P_EKF_WIN_FLUSH, sb);
-            launch_ekf_win_flush(sb, c->ekf, o.wd);
+            WinDesc fwd = o.wd;
+            fwd.cont = piece - 1;                                  // the set the last scan piece wrote
+            launch_ekf_win_flush(sb, c->ekf, fwd);
             prof_end(c);
             hipEvent_t ev = c->ev_win[c->ev_win_next++ & 15];
             HIP_TRY(c, hipEventRecord(ev, sb));

@@ -33,8 +33,8 @@ constexpr int kWinM = 20;              // landmarks per window frame at most (s 
 constexpr int kWinFrames = 64;         // frames per window at most
 struct WinDesc {                       // one window (kernel argument)
     int first_slot, K, m, s;           // slots first_slot .. first_slot + K - 1; s = 3 + 3 m
-    int cont, log0;                    // a run (frames on the same landmarks) is cut into chains of a few frames: cont = not the
-                                       // first chain of its run, log0 = frames of the run already logged
+    int cont, log0;                    // a run (frames on the same landmarks) is cut into chains of a few frames: cont = index of the
+                                       // piece within its run (0 = first; for the flush: of the LAST piece), log0 = frames already logged
     int li[kWinM];                     // state offset 3 + 3 index of every landmark, ascending (= pop order, aruco_slam.h:85-88)
 };
 

@@ -36,7 +36,11 @@ constexpr int WS = 66;                        // row stride (doubles) of a 64 x 
 constexpr int WIMG = 64 * WS;                 // doubles per image
 constexpr int WLOG_G = 0, WLOG_W = WIMG, WLOG_g = 2 * WIMG, WLOG_H3 = WLOG_g + 64, WLOG_HREC = WLOG_H3 + 16;
 constexpr int WLOG_STRIDE = WLOG_HREC + kWinM * 18;     // doubles per logged frame
-constexpr int WSM_LAM = 0, WSM_GAM = WIMG, WSM_PSI = 2 * WIMG, WSM_P = 3 * WIMG, WSM_psi = 4 * WIMG;    // layout of d_win_small
+// layout of d_win_small: TWO sets of the scan's accumulators (Lambda | Gamma | Psi | psi), then P.  A continuation piece of the scan
+// reads the set the previous piece wrote and writes the other one: its 4 x 4 workgroups share Lambda's column blocks, Gamma's row
+// blocks and psi, and a workgroup that finishes early must not overwrite what a workgroup that starts late still has to read.
+constexpr int WSM_SET = 3 * WIMG + 64;
+constexpr int WSM_LAM = 0, WSM_GAM = WIMG, WSM_PSI = 2 * WIMG, WSM_psi = 3 * WIMG, WSM_P = 2 * WSM_SET;
 constexpr int WCT = 512;                      // threads of the chain workgroup
 
 // development aid (make FLAGS+=-DASLAM_WIN_STAMPS): cycle stamps of the chain's phases, printed for one frame
@@ -53,7 +57,7 @@ constexpr int WCT = 512;                      // threads of the chain workgroup
 #endif
 
 size_t ekf_win_log_doubles() { return (size_t)WLOG_STRIDE * kWinFrames + 512; }   // + slack: the scan stages whole 16-byte x 256-thread passes
-size_t ekf_win_small_doubles() { return (size_t)4 * WIMG + 64; }
+size_t ekf_win_small_doubles() { return (size_t)2 * WSM_SET + WIMG; }
 
 // Gauss-Jordan image layout: element (r, c) of the 64 x 64 image.  Column-major with the rows of every 16-row tile regrouped so
 // that the four rows one lane holds of an MFMA accumulator tile (r = 16 g + lk + 4 reg) are neighbours: 16-byte LDS accesses.
@@ -474,12 +478,14 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
     const int li = lane & 15, lk = lane >> 4;
     const int bj = blockIdx.x, bi = blockIdx.y;
     const int m = wd.m, n3 = 3 * m;
-    double* small = E.d_win_small;
+    // wd.cont = index of this piece within its run (0 = first): piece p reads set (p - 1) & 1 and writes set p & 1
+    const double* rsmall = E.d_win_small + ((wd.cont - 1) & 1) * WSM_SET;
+    double* small = E.d_win_small + (wd.cont & 1) * WSM_SET;
     if (wd.cont) {                                                  // the run goes on: the accumulators as the previous scan left them
-        for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; sLam[r][c] = small[WSM_LAM + r * WS + 16 * bj + c]; }
-        for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; sGam[r][c] = small[WSM_GAM + (16 * bi + r) * WS + c]; }
-        { const int r = tid >> 4, c = tid & 15; sPsi[r][c] = small[WSM_PSI + (16 * bi + r) * WS + 16 * bj + c]; }
-        if (tid < 16) spsi[tid] = small[WSM_psi + 16 * bi + tid];
+        for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; sLam[r][c] = rsmall[WSM_LAM + r * WS + 16 * bj + c]; }
+        for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; sGam[r][c] = rsmall[WSM_GAM + (16 * bi + r) * WS + c]; }
+        { const int r = tid >> 4, c = tid & 15; sPsi[r][c] = rsmall[WSM_PSI + (16 * bi + r) * WS + 16 * bj + c]; }
+        if (tid < 16) spsi[tid] = rsmall[WSM_psi + 16 * bi + tid];
     } else {                                                        // Lambda = Gamma = I, Psi = 0, psi = 0
         for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; sLam[r][c] = (r == 16 * bj + c && r < wd.s) ? 1.0 : 0.0; }
         for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; sGam[r][c] = (c == 16 * bi + r && c < wd.s) ? 1.0 : 0.0; }
@@ -598,7 +604,8 @@ __global__ __launch_bounds__(256) void k_ekf_win_flush(EkfState E, WinDesc wd) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int s = wd.s;
-    const double* small = E.d_win_small;
+    const double* small = E.d_win_small;                          // P_K
+    const double* acc_set = E.d_win_small + (wd.cont & 1) * WSM_SET;   // the accumulators as the run's LAST scan piece (index wd.cont) left them
     double sig[4][4];
 #pragma unroll
     for (int ri = 0; ri < 4; ri++)
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_flush(EkfState E, WinDesc wd) {
             const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
             sig[ri][reg] = (r < N && c < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
         }
-    for (int e = tid; e < WIMG; e += 256) sM[e] = small[WSM_PSI + e];
+    for (int e = tid; e < WIMG; e += 256) sM[e] = acc_set[WSM_PSI + e];
     for (int e = tid; e < 64 * 64; e += 256) {
         const int p = e >> 6, x = e & 63;
         sY[p][x] = (p < s && c0 + x < N) ? E.d_V[(size_t)p * ld + c0 + x] : 0.0;
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_flush(EkfState E, WinDesc wd) {
     if (anyRow) {
         // rows of S: (Lambda Y_0)[p][c]
         __syncthreads();
-        for (int e = tid; e < WIMG; e += 256) sM[e] = small[WSM_LAM + e];
+        for (int e = tid; e < WIMG; e += 256) sM[e] = acc_set[WSM_LAM + e];
         __syncthreads();
         v4d acc[4];
 #pragma unroll
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_flush(EkfState E, WinDesc wd) {
     if (anyCol) {
         // columns of S: (X_0 Gamma)[r][q] = sum_p X_0^T[p][r] Gamma[p][q]; formed as D[q][r] with A[i = q][k = p] = Gamma[p][q]
         __syncthreads();
-        for (int e = tid; e < WIMG; e += 256) sM[e] = small[WSM_GAM + e];
+        for (int e = tid; e < WIMG; e += 256) sM[e] = acc_set[WSM_GAM + e];
         __syncthreads();
         v4d acc[4];
 #pragma unroll
@@ -718,7 +725,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_flush(EkfState E, WinDesc wd) {
         }
     if (blockIdx.y == 0 && tid < 64 && r0 + tid < N && sRowPos[tid] < 0) {
         double acc = 0;
-        for (int p = 0; p < s; p++) acc += sX[p][tid] * small[WSM_psi + p];
+        for (int p = 0; p < s; p++) acc += sX[p][tid] * acc_set[WSM_psi + p];
         E.d_mu[r0 + tid] += acc;                                   // mu_R += X_0 psi
     }
 }

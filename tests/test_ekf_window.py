@@ -119,6 +119,19 @@ def test_windows_match_the_literal_transcription(name):
     assert np.allclose(mu, mu2, rtol=1e-10, atol=1e-12) and np.abs(S - S2).max() <= 1e-10 * np.abs(S).max()
 
 
+@pytest.mark.parametrize("piece", [2, 3])
+def test_scan_continuation_pieces_read_the_previous_piece(piece, monkeypatch):
+    """A run is cut into chain pieces; the scan of a continuation piece must read the accumulators of the PREVIOUS piece whatever
+    order its 16 workgroups run in.  (They alternate between two sets: with one set a workgroup that finished early overwrote
+    what a late one still had to read - a matter of timing on the device, deterministic on the emulation with short pieces.)
+    ASLAM_WIN_PIECE shortens the pieces; the second run drops landmarks of the first."""
+    monkeypatch.setenv("ASLAM_WIN_PIECE", str(piece))
+    for groups in ([(6, list(range(10)), False), (5, list(range(5, 15)), False)],
+                   [(6, list(range(20)), False), (5, list(range(5, 20)), False)]):
+        frames, exp = make_case(2, groups, 25)
+        run_device(frames, exp, batch=len(frames))
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5])
 def test_windows_with_small_batches(batch):
     """windows never span calls: any batching gives the reference's result after every call"""
