@@ -25,6 +25,7 @@ using namespace aslam;
 
 namespace {
 
+constexpr int kWinLastPiece = 2;        // frames of a run's last chain piece (its scan and the flush are what the next window waits for)
 constexpr int kWinChainFrames = 8;      // frames per chain kernel of a run (its log is replayed meanwhile)
 
 enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
@@ -805,11 +806,16 @@ int finalize_pending(aslam_ctx* c) {
             // the replay of each piece's log (scan) and the run's single pass over Sigma (flush) go to a second stream, so
             // that only the last piece's scan and the flush are not hidden behind the chain.
             hipStream_t sa = c->stream_ekf, sb = c->stream_win;
+            // The chain of the NEXT window waits for this run's last scan and the flush: the last piece is kept short (kWinLastPiece
+            // frames), so that the scan in front of the flush has little left to replay.
             int piece = 0;
-            for (int k0 = 0; k0 < o.wd.K; k0 += c->win_piece, piece++) {
+            for (int k0 = 0, kn = 0; k0 < o.wd.K; k0 += kn, piece++) {
+                const int left = o.wd.K - k0;
+                kn = std::min(c->win_piece, left);
+                if (kn == left && kn > kWinLastPiece) kn -= kWinLastPiece;
                 WinDesc sub = o.wd;
                 sub.first_slot = o.wd.first_slot + k0;
-                sub.K = std::min(c->win_piece, o.wd.K - k0);
+                sub.K = kn;
                 sub.cont = piece;                                  // index of the piece: the scan alternates between two accumulator sets
                 sub.log0 = k0;
                 prof_begin(c, P_EKF_WIN_CHAIN, sa);
