@@ -134,6 +134,7 @@ _SIGS = {
     "aslam_debug_inject_observations": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _dp, _dp]),
     "aslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aslam_profile_reset": (C.c_int, [C.c_void_p]),
+    "aslam_get_plan_stats": (C.c_int, [C.c_void_p, _llp]),
     "aslam_profile_get": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_char_p), _ip, _dp]),
     "aslam_synth_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _ip, _dp, C.c_double, C.c_int,
                                      C.c_int, C.c_uint, C.c_int, _u8p]),
@@ -483,6 +484,12 @@ class Context:
 
     def profile_reset(self):
         self._ck(self.lib.aslam_profile_reset(self.h))
+
+    def plan_stats(self):
+        """frames fused inside windows / on the per-frame chain, windows formed, frames left to the device's own plan (since profile_reset)"""
+        out = np.zeros(4, np.int64)
+        self._ck(self.lib.aslam_get_plan_stats(self.h, _ptr(out, _llp)))
+        return dict(frames_in_windows=int(out[0]), frames_per_frame_chain=int(out[1]), windows=int(out[2]), frames_device_planned=int(out[3]))
 
     def profile_get(self):
         names = (C.c_char_p * 32)(); calls = np.zeros(32, np.int32); ms = np.zeros(32)

@@ -125,6 +125,7 @@ struct aslam_ctx {
     std::vector<HostLast> m_last;         // host mirror of last_observed_marker_ (NaN z = unset)
     bool mirror_dirty = true;             // the device planned frames the host could not follow: read the tables back before planning
     int ekf_lo = 0, ekf_hi = 0;           // union of the slot ranges of EKF work enqueued since the last wait on ev_ekf
+    long long plan_stats[4] = {0, 0, 0, 0};   // frames inside windows, frames on the per-frame chain, windows, frames left to the device's own plan
 
     // map gather over RCCL without torch (aslam_comm_*): librccl is dlopen'ed on first use
     void* comm = nullptr;
@@ -284,6 +285,22 @@ int configure_frames(aslam_ctx* c, int rows, int cols, int channels) {
 
 int check_slot_range(aslam_ctx* c, int first, int count) {
     if (first < 0 || count <= 0 || first + count > c->max_batch) return fail(c, ASLAM_E_INVALID, "slot range outside [0, max_batch)");
+    return ASLAM_OK;
+}
+
+// Before the host rewrites the inputs of slots [slot0, slot0 + n) (frames, encoder samples, injected observations): work that
+// still reads them must have finished.  A batch whose EKF work is still pending (run_staged defers it by one call) reads its
+// encoder samples and observations only when it is finalised, and the chain kernels read d_enc when they run.
+int quiesce_slots(aslam_ctx* c, int slot0, int n) {
+    if (c->pend.active && slot0 < c->pend.first + c->pend.count && c->pend.first < slot0 + n) {
+        int r = finalize_pending(c);
+        if (r) return r;
+    }
+    if (c->ekf_count > 0 && slot0 < c->ekf_hi && c->ekf_lo < slot0 + n) {
+        HIP_TRY(c, hipEventSynchronize(c->ev_ekf));
+        c->ekf_count = 0;
+    }
+    if (c->last_detect && slot0 < c->last_first + c->last_count && c->last_first < slot0 + n) HIP_TRY(c, hipEventSynchronize(c->ev_detect));
     return ASLAM_OK;
 }
 
@@ -630,6 +647,8 @@ int aslam_stage_frames(aslam_ctx* c, int slot0, const uint8_t* frames, int nfram
         if (r) return r;
     }
     if (step < (size_t)cols * channels) return fail(c, ASLAM_E_INVALID, "step smaller than a row");
+    r = quiesce_slots(c, slot0, nframes);
+    if (r) return r;
     c->in_frame_bytes = (size_t)rows * cols * channels;
     for (int f = 0; f < nframes; f++)
         HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)(slot0 + f) * c->in_frame_bytes, (size_t)cols * channels,
@@ -642,6 +661,8 @@ int aslam_stage_frames(aslam_ctx* c, int slot0, const uint8_t* frames, int nfram
 int aslam_stage_encoders(aslam_ctx* c, int slot0, int n, const double* wl, const double* wr, const double* dt) {
     if (!c || !wl || !wr || !dt) return fail(c, ASLAM_E_INVALID, "null argument");
     int r = check_slot_range(c, slot0, n);
+    if (r) return r;
+    r = quiesce_slots(c, slot0, n);              // a pending / in-flight batch still reads the samples in these slots
     if (r) return r;
     std::vector<double> h((size_t)3 * n);
     for (int i = 0; i < n; i++) { h[3 * i] = wl[i]; h[3 * i + 1] = wr[i]; h[3 * i + 2] = dt[i]; }
@@ -736,6 +757,7 @@ int finalize_pending(aslam_ctx* c) {
             if (std::getenv("ASLAM_DEBUG_PLAN")) std::fprintf(stderr, "plan frame %d: nM %d left to the device\n", f, nM);
             close_window();
             device_plans = true;
+            c->plan_stats[3]++;
             c->mirror_dirty = true;
             Op o{};
             o.frame = f; o.predict = predict; o.wd.K = 0;
@@ -795,6 +817,10 @@ int finalize_pending(aslam_ctx* c) {
                                   hipMemcpyHostToDevice, c->stream_ekf));
         HIP_TRY(c, hipEventRecord(c->ev_idx, c->stream_ekf));
         c->ev_idx_set = true;
+    }
+    for (const Op& o : ops) {
+        if (o.wd.K == 0) c->plan_stats[1]++;
+        else { c->plan_stats[0] += o.wd.K; c->plan_stats[2]++; }
     }
     for (const Op& o : ops) {
         if (o.wd.K == 0) {
@@ -871,6 +897,7 @@ int run_staged(aslam_ctx* c, int first, int count, int with_ekf, hipEvent_t wait
             c->is_init = true;
             r = run_ekf_frame(c, first + i, e[0], e[1], e[2], predict);
             if (r) return r;
+            c->plan_stats[1]++;
         }
         HIP_TRY(c, hipEventRecord(c->ev_ekf, c->stream_ekf));
         note_ekf_range(c, first, count);
@@ -1081,6 +1108,7 @@ int aslam_set_dictionary_bytes(aslam_ctx* c, int marker_size, int n_markers, int
 
 int aslam_add_encoder(aslam_ctx* c, double wl, double wr, double t_now) {
     if (!c) return ASLAM_E_INVALID;
+    { int rp = finalize_pending(c); if (rp) return rp; }     // a pending batch arms the filter itself (is_init is set there)
     if (!c->is_init) {                       // aruco_slam.cpp:24-29
         c->last_time = t_now;
         c->is_init = true;
@@ -1088,7 +1116,6 @@ int aslam_add_encoder(aslam_ctx* c, double wl, double wr, double t_now) {
     }
     double dt = t_now - c->last_time;        // aruco_slam.cpp:31-32
     c->last_time = t_now;
-    { int rp = finalize_pending(c); if (rp) return rp; }
     launch_ekf_predict_only(c->stream_ekf, c->ekf, c->sp, wl, wr, dt);
     HIP_TRY(c, hipGetLastError());
     return ASLAM_OK;
@@ -1096,9 +1123,9 @@ int aslam_add_encoder(aslam_ctx* c, double wl, double wr, double t_now) {
 
 int aslam_add_image(aslam_ctx* c, const uint8_t* px, int rows, int cols, int channels, size_t step) {
     if (!c || !px) return fail(c, ASLAM_E_INVALID, "null argument");
-    if (!c->is_init) return ASLAM_OK;        // aruco_slam.cpp:84-85: nothing happens before the first encoder message
     int r = finalize_pending(c);
     if (r) return r;
+    if (!c->is_init) return ASLAM_OK;        // aruco_slam.cpp:84-85: nothing happens before the first encoder message
     c->mirror_dirty = true;                  // planned on the device: the host's copy of the tables is stale afterwards
     r = aslam_stage_frames(c, 0, px, 1, rows, cols, channels, step, 0);
     if (r) return r;
@@ -1764,10 +1791,18 @@ int aslam_profile_enable(aslam_ctx* c, int on) {
     }
     return ASLAM_OK;
 }
+int aslam_get_plan_stats(aslam_ctx* c, long long out[4]) {
+    if (!c || !out) return ASLAM_E_INVALID;
+    int r = finalize_pending(c);
+    if (r) return r;
+    for (int i = 0; i < 4; i++) out[i] = c->plan_stats[i];
+    return ASLAM_OK;
+}
 int aslam_profile_reset(aslam_ctx* c) {
     if (!c) return ASLAM_E_INVALID;
     sync_streams(c);
     prof_collect(c);
+    for (int i = 0; i < 4; i++) c->plan_stats[i] = 0;
     for (int i = 0; i < P_COUNT; i++) { c->prof_calls[i] = 0; c->prof_ms[i] = 0; }
     return ASLAM_OK;
 }
@@ -1798,6 +1833,8 @@ int aslam_synth_render(aslam_ctx* c, int slot, int rows, int cols, const double 
         if (r) return r;
     }
     c->in_frame_bytes = (size_t)rows * cols;
+    r = quiesce_slots(c, slot, 1);
+    if (r) return r;
     const int nc = c->dict_ms + 2;
     std::vector<SynthMarker> mk(n_markers);
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];

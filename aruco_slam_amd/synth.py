@@ -108,6 +108,12 @@ class SceneConfig:
     # cv::aruco::DetectorParameters fields that differ from the OpenCV 3.2.0 defaults for this scene (applied to the library
     # AND to the oracle by whoever drives the scene: apply_detector())
     detector: dict = field(default_factory=dict)
+    # "panel": PanelWorld (the visible set is constant over a panel approach); "ring": RingWorld (the visible set slides)
+    kind: str = "panel"
+    ring_radius: float = 2.6       # RingWorld: radius of the landmark ring
+    ring_robot_radius: float = 0.3  # ... and of the robot's own circle inside it
+    ring_lap_frames: int = 500     # frames per revolution (heading advances 2 pi / ring_lap_frames per frame)
+    ring_yaw_jitter_deg: float = 10.0
 
 
 CONFIGS = {
@@ -133,6 +139,9 @@ CONFIGS = {
     "cfg3": SceneConfig(rows=1080, cols=1920, f=1000.0, grid=(10, 5), n_panels=20, col_spacing=0.36, row_spacing=0.34,
                         tz_far=2.3, tz_near=2.0, max_yaw_deg=20.0, seed=2, step=0.025,
                         detector={"polygonalApproxAccuracyRate": 0.03, "doCornerRefinement": 1}),
+    # the headline sizes (1280x720, 20 markers in view, 200 landmarks) on a world whose visible set SLIDES: 50 columns x 4 rows
+    # of markers on a ring around the robot, rows staggered, so that one marker leaves and another enters every 2.5 frames
+    "cfg2_sliding": SceneConfig(kind="ring", grid=(5, 4), n_panels=10, detector={"polygonalApproxAccuracyRate": 0.03, "doCornerRefinement": 1}),
 }
 
 
@@ -217,6 +226,77 @@ class PanelWorld:
         theta = norm_angle(phi) if phi < 2 * math.pi else 0.0
         return Frame(ids=self.ids[sel].copy(), poses=poses, wl=wl, wr=wr, dt=cfg.dt, true_pose=(p[0], p[1], theta),
                      landmark_index=sel)
+
+
+class RingWorld:
+    """L = n_cols x n_rows markers on a ring of radius `ring_radius` that face its centre; the robot drives a small circle
+    around the centre with CONSTANT wheel speeds ("constant wheel speeds ... camera pose advanced with the same
+    midpoint model"), camera looking along its heading.  A marker is in view while its ring angle is within half a window
+    (grid[0] column spacings wide) of the heading; the rows are staggered by 1 / n_rows of a column spacing, so every frame sees
+    exactly M = grid[0] * grid[1] markers and the visible SET changes by one marker every (column spacing / n_rows) of
+    heading: the sliding-visibility stream the windowed EKF must not depend on being absent."""
+
+    def __init__(self, cfg: SceneConfig):
+        self.cfg = cfg
+        gc, gr = cfg.grid
+        self.M = gc * gr
+        self.L = self.M * cfg.n_panels
+        self.n_cols, self.n_rows = self.L // gr, gr
+        self.K = camera_matrix(cfg.rows, cfg.cols, cfg.f)
+        rng = np.random.RandomState(cfg.seed + 77)
+        self.ids = np.array(unambiguous_ids(self.L), np.int32)
+        self.dalpha = 2 * math.pi / self.n_cols
+        self.half_window = 0.5 * gc * self.dalpha
+        col = np.arange(self.L) // gr
+        row = np.arange(self.L) % gr
+        # + 0.37 of a stagger step: no marker ever sits exactly on the window's edge at a frame's heading
+        self.alpha = (col + (row + 0.37) / gr) * self.dalpha
+        self.height = ((gr - 1) / 2.0 - row) * cfg.row_spacing
+        jitter = np.deg2rad(rng.uniform(-cfg.ring_yaw_jitter_deg, cfg.ring_yaw_jitter_deg, self.L))
+        self.theta_w = np.array([norm_angle(norm_angle(a + math.pi + j)) for a, j in zip(self.alpha, jitter)])
+        self.pos = cfg.ring_radius * np.stack([np.cos(self.alpha), np.sin(self.alpha)], 1)
+        self.world = np.concatenate([self.pos, self.theta_w[:, None]], 1)
+        # the robot's trajectory = the reference's own motion model (aruco_slam.cpp:35-52) integrated with constant wheel speeds
+        self.dtheta = 2 * math.pi / cfg.ring_lap_frames
+        ds = cfg.ring_robot_radius * self.dtheta
+        ds_r, ds_l = ds + cfg.b * self.dtheta, ds - cfg.b * self.dtheta
+        self.wr, self.wl = ds_r / (cfg.kr * cfg.dt), ds_l / (cfg.kl * cfg.dt)
+        pose = np.zeros((cfg.ring_lap_frames, 3))
+        x, y, th = cfg.ring_robot_radius * math.sin(0.0), -cfg.ring_robot_radius * math.cos(0.0), 0.0
+        for i in range(cfg.ring_lap_frames):
+            pose[i] = (x, y, th)
+            x += ds * math.cos(th + 0.5 * self.dtheta)
+            y += ds * math.sin(th + 0.5 * self.dtheta)
+            th = (i + 1) * self.dtheta
+        self.pose = pose
+
+    def lap_length(self):
+        return self.cfg.ring_lap_frames
+
+    def frame(self, index):
+        cfg = self.cfg
+        i = index % self.lap_length()
+        px, py, phi = self.pose[i]
+        u = np.array([math.cos(phi), math.sin(phi)])
+        n = np.array([-math.sin(phi), math.cos(phi)])
+        rel = (self.alpha - phi + math.pi) % (2 * math.pi) - math.pi
+        sel = np.nonzero(np.abs(rel) < self.half_window)[0]
+        poses = np.zeros((len(sel), 12))
+        for a, li in enumerate(sel):
+            d = self.pos[li] - np.array([px, py])
+            zx, zy = float(d @ u), float(d @ n)
+            t = (-(zy - cfg.r2c[1]), -self.height[li], zx - cfg.r2c[0])
+            psi = (phi + math.pi - self.theta_w[li] + math.pi) % (2 * math.pi) - math.pi       # observed at theta = pi - psi
+            R, t = marker_pose(t, psi)
+            poses[a, :9] = R.reshape(-1)
+            poses[a, 9:] = t
+        wl, wr = (0.0, 0.0) if index == 0 else (self.wl, self.wr)    # the first sample only arms the filter (aruco_slam.cpp:24-29)
+        return Frame(ids=self.ids[sel].copy(), poses=poses, wl=wl, wr=wr, dt=cfg.dt, true_pose=(px, py, norm_angle(phi)),
+                     landmark_index=sel)
+
+
+def make_world(cfg: SceneConfig):
+    return RingWorld(cfg) if cfg.kind == "ring" else PanelWorld(cfg)
 
 
 def simple_scene(rows, cols, f, n_markers, seed=0, tz=(1.2, 2.6), marker_length=0.27, max_yaw_deg=30.0):

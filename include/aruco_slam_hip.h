@@ -133,7 +133,11 @@ int aslam_get_landmark_ids(aslam_ctx* ctx, int* L, int* ids);
  * aslam_stage_encoders stores, per slot, the encoder sample (wl, wr, dt) that precedes that frame;
  * aslam_run_staged(first, count, with_ekf) then runs (with_ekf: 0 detection+pose only, 1 full path, 2 EKF steps only), entirely on the device and asynchronously on the context's
  * stream: detection + pose for all `count` frames batched, followed (with_ekf != 0) by `count` sequential
- * addEncoder(dt) + addImage EKF steps.  aslam_sync waits and reports device-side overflow. */
+ * addEncoder(dt) + addImage EKF steps.  aslam_sync waits and reports device-side overflow.
+ * Re-staging rule: aslam_run_staged returns before the batch has run (its EKF work is even enqueued one call
+ * later, once its observations have reached the host).  aslam_stage_frames / aslam_stage_encoders on slots a
+ * submitted batch still reads first finish that batch's use of them (they enqueue the deferred EKF work and
+ * wait for it), so the new samples can never reach the old batch; slots outside the range are not waited for. */
 int aslam_stage_frames(aslam_ctx* ctx, int slot0, const uint8_t* frames, int nframes, int rows, int cols,
                        int channels, size_t step_bytes, size_t frame_stride_bytes);
 int aslam_stage_encoders(aslam_ctx* ctx, int slot0, int n, const double* wl, const double* wr, const double* dt);
@@ -234,6 +238,10 @@ int aslam_debug_inject_observations(aslam_ctx* ctx, int slot, int n, const int* 
 int aslam_profile_enable(aslam_ctx* ctx, int on);
 int aslam_profile_reset(aslam_ctx* ctx);
 int aslam_profile_get(aslam_ctx* ctx, int max, const char** names, int* calls, double* total_ms);
+/* how the frames submitted with an EKF step since the last aslam_profile_reset were scheduled: out[0] frames fused inside
+ * windows (ekf_window.hip), out[1] frames on the per-frame chain, out[2] windows formed, out[3] frames whose bookkeeping was left
+ * to the device (a new landmark, one id twice) - the windowed path is an optimisation, never a different result. */
+int aslam_get_plan_stats(aslam_ctx* ctx, long long out[4]);
 
 /* deterministic synthetic frame renderer (input generation for tests and bench; not on the hot path).
  * markers: per marker 12 doubles = rotation (row-major 3x3, marker->camera) then translation;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # one gpurun call: GPU test suite, then bench.py (skipped if the tests were killed at their time limit)
-tag=${1:-r02}
+tag=${1:-r03}
 mkdir -p gpurun_out
 timeout -k 10 ${TEST_TIMEOUT:-800} python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_tests.log 2>&1
 rc=$?

@@ -1,13 +1,15 @@
-"""Condense gpurun_out/prof_<tag>/ (scripts/profile_round.sh) into profiles/: kernel stats CSV, PMC traffic JSON, bench JSON."""
+"""Condense gpurun_out/prof_<tag>_<config>/ (scripts/profile_round.sh) into profiles/: kernel stats CSV, PMC traffic JSON.
+usage: python scripts/pmc_summary.py <tag> [config=cfg2]"""
 import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 tag = sys.argv[1]
-src = os.path.join("gpurun_out", "prof_" + tag)
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+src = os.path.join("gpurun_out", f"prof_{tag}_{cfg}")
 os.makedirs("profiles", exist_ok=True)
 st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if st:
-    shutil.copy(st[0], os.path.join("profiles", f"{tag}_bench_kernel_stats.csv"))
+    shutil.copy(st[0], os.path.join("profiles", f"{tag}_{cfg}_kernel_stats.csv"))
 kern = defaultdict(lambda: defaultdict(float))
 launch = defaultdict(int)
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -20,20 +22,17 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
             kern[k][name] += float(row["Counter_Value"])
             if name == "FETCH_SIZE":
                 launch[k] += 1
-FRAMES_PER_STEP = 320          # bench.py default: one lap of cfg2 per step, every detection launch covers one step
-FRAMES_PER_LAUNCH = {"k_ekf_win_chain": 8, "k_ekf_win_scan": 8, "k_ekf_win_flush": 32}     # chain pieces of 8 frames, runs of 32
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-extra`; "
-               "KB per launch, uncorrected (gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section: "
-               "bench.py doubles it); frames_per_launch = frames one launch of the kernel covers in that command",
-       "config": "cfg2", "ekf": True, "frames_per_step": FRAMES_PER_STEP,
-       "kernels": {}}
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python3 bench.py --config <config> --steps 3 --warmup 1 "
+               "--cpu-sample 0 --no-extra`; KB per launch averaged over every launch of the kernel in that command, uncorrected (gfx950: "
+               "FETCH_SIZE counts 1/2 of wide coalesced reads, MI355X_MICROARCH.md HBM section: bench.py doubles it)",
+       "config": cfg, "ekf": cfg != "cfg5", "kernels": {}}
 for k in kern:
     n = max(launch[k], 1)
-    fpl = FRAMES_PER_LAUNCH.get(k, 1 if k.startswith("k_ekf") else FRAMES_PER_STEP)
     out["kernels"][k] = {"FETCH_SIZE_KB_per_launch": round(kern[k]["FETCH_SIZE"] / n, 2), "launches": launch[k],
-                         "WRITE_SIZE_KB_per_launch": round(kern[k]["WRITE_SIZE"] / n, 2), "frames_per_launch": fpl}
-json.dump(out, open(os.path.join("profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
-b = os.path.join(src, "bench_default.json")
-if os.path.exists(b):
-    shutil.copy(b, os.path.join("profiles", f"{tag}_bench_default.json"))
+                         "WRITE_SIZE_KB_per_launch": round(kern[k]["WRITE_SIZE"] / n, 2)}
+json.dump(out, open(os.path.join("profiles", f"{tag}_{cfg}_pmc_traffic.json"), "w"), indent=1)
+for nm in ("bench_stats.json",):
+    b = os.path.join(src, nm)
+    if os.path.exists(b) and os.path.getsize(b) > 0:
+        shutil.copy(b, os.path.join("profiles", f"{tag}_{cfg}_bench_under_rocprof.json"))
 print("kernels:", {k: v for k, v in out["kernels"].items() if k.startswith("k_")})

@@ -58,9 +58,12 @@ def check_poses(ids, corners, rv_g, tv_g, K, D, marker_length=0.27, rtol=POSE_RT
         assert np.allclose(tv, tv_g[j], rtol=rtol, atol=rtol * 1e-2), f"tvec differs for marker {ids[j]}"
 
 
-def run_slam_sequence(cfg, n_frames, batch, literal, noise_amp=2, per_frame_check=False, ctx_kwargs=None, D=None):
-    """Drive the HIP path (staged stream API) and the oracle over the same synthetic tour; compare after each batch."""
-    w = synth.PanelWorld(cfg)
+def run_slam_sequence(cfg, n_frames, batch, literal, noise_amp=2, per_frame_check=False, ctx_kwargs=None, D=None, detector="scene"):
+    """Drive the HIP path (staged stream API) and the oracle over the same synthetic tour; compare after each batch.
+    detector: "scene" = the scene's own DetectorParameters profile (synth.CONFIGS), "reference" = the defaults, which is what
+    the reference runs (aruco_slam.cpp:313).  Nothing is forced either way: per frame, the detections, the observations that pass
+    the gates (aruco_slam.cpp:327-333, 367-368) and the augment / update / stationary counts must EQUAL the oracle's."""
+    w = synth.make_world(cfg)
     D = np.zeros(5) if D is None else D
     kw = dict(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=batch, max_landmarks=max(w.L + 8, 16),
               r2c_t=(cfg.r2c[0], cfg.r2c[1], 0.0))
@@ -69,9 +72,10 @@ def run_slam_sequence(cfg, n_frames, batch, literal, noise_amp=2, per_frame_chec
     ctx.set_camera(w.K, D)
     o = orc.Slam(r2c_tx=cfg.r2c[0], r2c_ty=cfg.r2c[1], literal=literal)
     o.set_camera(w.K, D)
-    synth.apply_detector(cfg, ctx, o)
+    if detector == "scene":
+        synth.apply_detector(cfg, ctx, o)
     t_now = 0.0
-    stats = dict(frames=0, updates=0, augments=0, stationary=0, max_mu=0.0, max_sigma=0.0)
+    stats = dict(frames=0, updates=0, augments=0, stationary=0, max_mu=0.0, max_sigma=0.0, frames_short_of_M=0, markers=0, fused_total=0)
     for f0 in range(0, n_frames, batch):
         nb = min(batch, n_frames - f0)
         frs = [w.frame(f0 + i) for i in range(nb)]
@@ -82,6 +86,7 @@ def run_slam_sequence(cfg, n_frames, batch, literal, noise_amp=2, per_frame_chec
         for first, cnt in groups:
             ctx.run_staged(first, cnt, with_ekf=True)
             ctx.sync()
+            expect_stats = []
             for i in range(first, first + cnt):
                 t_now += frs[i].dt
                 o.add_encoder(frs[i].wl, frs[i].wr, t_now)
@@ -90,6 +95,16 @@ def run_slam_sequence(cfg, n_frames, batch, literal, noise_amp=2, per_frame_chec
                 g_ids, g_c = ctx.get_slot_detections(i)[:2]
                 assert np.array_equal(d_ids, g_ids), f"frame {f0 + i}: marker ids differ"
                 assert np.array_equal(d_c, g_c), f"frame {f0 + i}: marker corners differ"
+                # gate decisions (range gate aruco_slam.cpp:327-333, covariance gate :367-368): the observations that reach the queue
+                fi, _, fa, _, _ = o.log_observations()
+                r_ids, r_valid, _, _ = ctx.get_slot_raw_observations(i)
+                assert sorted(r_ids[r_valid == 1].tolist()) == sorted(fi.tolist()), f"frame {f0 + i}: gate decisions differ"
+                expect_stats.append([len(d_ids), int((fa == 0).sum()), int((fa == 1).sum()), int((fa == 2).sum())])
+                stats["frames_short_of_M"] += int(len(fi) < w.M)
+                stats["markers"] += len(d_ids)
+                stats["fused_total"] += int((fa == 1).sum())
+            got_stats = ctx.get_slot_ekf_stats(first, cnt)
+            assert np.array_equal(got_stats, np.array(expect_stats)), "per-frame detections / augments / updates / stationary counts differ"
             oi, ox, oa, oz, oR = o.log_observations()
             gi, gx, ga, gz, gR = ctx.get_observations()
             assert np.array_equal(oi, gi), "pop order (ids) differs"

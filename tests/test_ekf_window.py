@@ -148,3 +148,27 @@ def test_windows_on_gpu(name):
     (mu, S), prof, worst = run_device(frames, exp, batch=len(frames))
     assert prof["k_ekf_win_chain"][0] > 0
     run_device(frames, exp, batch=3)
+
+
+def test_restaging_slots_of_a_submitted_batch_does_not_reach_it():
+    """aslam_run_staged returns before the batch's EKF work is even enqueued (it is deferred by one call); encoder samples staged
+    into the same slots afterwards, before any synchronisation, must not be read by the batch that was submitted before them
+    (include/aruco_slam_hip.h, re-staging rule)."""
+    seed, groups, n_land = CASES["two_groups"]
+    frames, exp = make_case(seed, groups, n_land)
+    nfr = len(frames)
+    ctx = capi.Context(max_rows=64, max_cols=64, max_batch=nfr, persistent_waves=4, max_landmarks=40, r2c_t=(0.1, -0.05, 0.0))
+    ctx.set_camera(K, D)
+    t = [fr["t"] for fr in frames]
+    ctx.stage_encoders([fr["wl"] for fr in frames], [fr["wr"] for fr in frames], [0.0] + [t[i] - t[i - 1] for i in range(1, nfr)])
+    for f, fr in enumerate(frames):
+        obs = fr["obs"]
+        ctx.inject_observations(f, fr["ids"], [0 if o is None else 1 for o in obs],
+                                np.array([np.zeros(3) if o is None else o["z"] for o in obs]).reshape(-1, 3),
+                                np.array([np.ones(3) if o is None else np.diag(o["R"]) for o in obs]).reshape(-1, 3))
+    ctx.run_staged(0, nfr, with_ekf=2)                                  # asynchronous; EKF work still pending
+    ctx.stage_encoders([9.0] * nfr, [-9.0] * nfr, [0.5] * nfr)         # the NEXT batch's samples into the same slots
+    ctx.sync()
+    mu, S = ctx.get_state()
+    assert np.allclose(mu, exp[-1]["mu"], rtol=1e-9, atol=1e-11), f"mu differs by {np.abs(mu - exp[-1]['mu']).max()}"
+    assert np.abs(S - exp[-1]["sigma"]).max() <= 1e-9 * np.abs(S).max()

@@ -114,6 +114,38 @@ def test_slam_sequence_cfg2_headline():
     assert (np.diag(S) > 0).all()
 
 
+@pytest.mark.parametrize("name", ["cfg2", "cfg3"])
+def test_reference_default_detector_whole_lap(name):
+    """THE configuration the reference runs: cv::aruco::detectMarkers with default DetectorParameters (aruco_slam.cpp:313:
+    polygonalApproxAccuracyRate 0.05, integer corners), full size, one whole lap through the augment path plus frames of the second
+    lap.  Nothing is forced: with these defaults some markers lose to their inner border contour and some observations to the
+    covariance gate (aruco_slam.cpp:367-368), so frames fuse FEWER than M corrections; per frame the ids / corners, the gate
+    decisions and the augment / update / stationary counts, and per batch the pop order, R, mu and Sigma must equal the oracle's."""
+    cfg = synth.CONFIGS[name]
+    w = synth.make_world(cfg)
+    n = w.lap_length() + 2 * w.frames_per_panel
+    stats, ctx, o = pc.run_slam_sequence(cfg, n, batch=16, literal=False, detector="reference",
+                                         ctx_kwargs=dict(max_updates_per_frame=24 if w.M <= 24 else 64))
+    assert stats["max_sigma"] < pc.TIGHT
+    assert stats["frames_short_of_M"] > 0, "the defaults were expected to cost observations (DESIGN.md §5)"
+    assert stats["fused_total"] > 0.8 * w.M * (n - w.cfg.n_panels)
+    mu, S = ctx.get_state()
+    assert np.abs(S - S.T).max() <= 1e-9 * np.abs(S).max() and (np.diag(S) > 0).all()
+
+
+@pytest.mark.parametrize("detector", ["scene", "reference"])
+def test_sliding_visibility_world(detector):
+    """the headline sizes on a world whose visible set changes every 2.5 frames (synth.RingWorld): a lap that builds the 200-landmark
+    map one marker at a time, then frames of the second lap (every marker known, the landmark set sliding under the windows)"""
+    cfg = synth.CONFIGS["cfg2_sliding"]
+    w = synth.make_world(cfg)
+    n = w.lap_length() + 60
+    stats, ctx, o = pc.run_slam_sequence(cfg, n, batch=20, literal=False, detector=detector)
+    assert stats["landmarks"] == w.L if detector == "scene" else stats["landmarks"] > 0.8 * w.L
+    assert stats["max_sigma"] < pc.TIGHT
+    assert stats["fused_total"] > 12 * n
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("waves", [256, 4096, 8192])
 def test_results_do_not_depend_on_the_number_of_work_queue_waves(waves):
