@@ -20,13 +20,14 @@
 #include <cstdio>
 #include <cmath>
 #include <algorithm>
+#include <iterator>
 
 using namespace aslam;
 
 namespace {
 
 constexpr int kWinLastPiece = 2;        // frames of a run's last chain piece (its scan and the flush are what the next window waits for)
-constexpr int kWinChainFrames = 8;      // frames per chain kernel of a run (its log is replayed meanwhile)
+constexpr int kWinChainFrames = 8;      // frames per chain kernel of a window (its log is replayed meanwhile); <= kWinPieceMax
 
 enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
               P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_EKF_MID64, P_EKF_WIN_CHAIN, P_EKF_WIN_SCAN, P_EKF_WIN_FLUSH, P_COUNT };
@@ -117,8 +118,7 @@ struct aslam_ctx {
     bool ev_idx_set = false;
     ObsRaw* h_obs = nullptr;              // pinned: max_batch x kMarkerMax
     unsigned* h_nm = nullptr;             // pinned: max_batch
-    unsigned char* h_obs_idx = nullptr;   // pinned: max_batch x kWinM, detection index of the j-th popped observation
-    unsigned char* d_obs_idx = nullptr;
+    WinFrame* h_win_frames = nullptr;     // pinned: max_batch frame plans (uploaded to ekf.d_win_frames per batch)
     std::vector<int> m_id2idx;            // host mirror of the id -> landmark table, valid unless mirror_dirty
     int m_L = 0;
     struct HostLast { int id; double z[3]; };
@@ -575,7 +575,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && hipMemset(c->d_nfinal, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_ncand, 0, sizeof(unsigned) * B) == hipSuccess;
     ok = ok && hipMemset(c->d_enc, 0, sizeof(double) * 3 * B) == hipSuccess;
-    ok = ok && ekf_alloc(c->ekf, init->max_landmarks, init->max_batch) == hipSuccess;
+    ok = ok && ekf_alloc(c->ekf, init->max_landmarks, init->max_batch, init->max_updates_per_frame) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_obs[0], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_obs[1], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_idx, hipEventDisableTiming) == hipSuccess;
@@ -583,8 +583,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     for (int i = 0; i < 16; i++) ok = ok && hipEventCreateWithFlags(&c->ev_win[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_obs), (size_t)B * kMarkerMax * sizeof(ObsRaw), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_nm), (size_t)B * sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_obs_idx), (size_t)B * kWinM, hipHostMallocDefault) == hipSuccess;
-    ok = ok && dalloc(&c->d_obs_idx, (size_t)B * kWinM) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_win_frames), (size_t)B * sizeof(WinFrame), hipHostMallocDefault) == hipSuccess;
     if (!ok) { aslam_destroy(c); return ASLAM_E_NO_DEVICE; }
     *out = c;
     return ASLAM_OK;
@@ -614,8 +613,7 @@ void aslam_destroy(aslam_ctx* c) {
     if (c->h_ring) hipHostFree(c->h_ring);
     if (c->h_obs) hipHostFree(c->h_obs);
     if (c->h_nm) hipHostFree(c->h_nm);
-    if (c->h_obs_idx) hipHostFree(c->h_obs_idx);
-    hipFree(c->d_obs_idx);
+    if (c->h_win_frames) hipHostFree(c->h_win_frames);
     for (int h = 0; h < 2; h++) if (c->ev_obs[h]) hipEventDestroy(c->ev_obs[h]);
     if (c->ev_idx) hipEventDestroy(c->ev_idx);
     for (int i = 0; i < 16; i++) if (c->ev_win[i]) hipEventDestroy(c->ev_win[i]);
@@ -697,8 +695,9 @@ int read_mirror(aslam_ctx* c) {
 
 // The EKF work of the pending batch: the host follows the reference's bookkeeping (checkLandmark, queue order, the
 // "stationary" test, aruco_slam.cpp:92-95, 192-198, 423-435) on the observations read back from the device and cuts the batch
-// into windows = runs of frames that fuse the same landmarks (ekf_window.hip); every other frame, and every frame the host
-// cannot decide (a marker id it does not know: a new landmark; one id twice), takes the per-frame chain, planned on the device.
+// into windows = runs of frames whose fused landmarks fit into one set S (ekf_window.hip); every other frame, and every frame
+// the host cannot decide (a marker id it does not know: a new landmark; one id twice), takes the per-frame chain, planned on the
+// device.  A window frame may fuse any subset of S and may drop "stationary" observations; S is the union over the window.
 int finalize_pending(aslam_ctx* c) {
     if (!c->pend.active) return ASLAM_OK;
     const aslam_ctx::Pending p = c->pend;
@@ -707,18 +706,23 @@ int finalize_pending(aslam_ctx* c) {
     if (c->mirror_dirty) { int r = read_mirror(c); if (r) return r; }
     if (c->ev_idx_set) HIP_TRY(c, hipEventSynchronize(c->ev_idx));          // the previous batch's upload has left the pinned rows
     HIP_TRY(c, hipStreamWaitEvent(c->stream_ekf, c->ev_obs[p.ev], 0));
-    struct Op { int frame; bool predict; WinDesc wd; };                     // wd.K == 0: per-frame chain for `frame`
+    struct FramePlan { std::vector<int> corr_idx, corr_det, pop_idx, pop_det, pop_act; int n_markers = 0; };
+    struct Op { int frame; bool predict; int K; std::vector<int> S; };      // K == 0: per-frame chain for `frame`; else a window of K frames on S
     std::vector<Op> ops;
-    WinDesc cur{};
-    cur.K = 0;
+    std::vector<FramePlan> plans(p.count);
+    // largest set S: contexts configured for few corrections per frame keep SP <= 128 (their chain steps stay cheap)
+    const int s_cap = c->ekf.win_sp_max >= 192 ? kWinSMax : 41;
+    int w_first = -1, w_K = 0;
+    std::vector<int> w_S;                                                   // sorted landmark indices of the open window
     bool device_plans = false;
     auto close_window = [&]() {
-        if (cur.K == 0) return;
+        if (w_K == 0) return;
         Op o{};
-        if (cur.K == 1) { o.frame = cur.first_slot; o.predict = true; o.wd.K = 0; }      // a lone frame: the per-frame chain is as good
-        else { o.frame = cur.first_slot; o.predict = true; o.wd = cur; }
+        o.frame = w_first; o.predict = true;
+        if (w_K == 1) o.K = 0;                                              // a lone frame: the per-frame chain is as good
+        else { o.K = w_K; o.S = w_S; }
         ops.push_back(o);
-        cur.K = 0;
+        w_K = 0; w_S.clear();
     };
     for (int f = p.first; f < p.first + p.count; f++) {
         const bool predict = c->is_init;            // addEncoder semantics (aruco_slam.cpp:24-29): the very first sample only arms the filter
@@ -760,12 +764,14 @@ int finalize_pending(aslam_ctx* c) {
             c->plan_stats[3]++;
             c->mirror_dirty = true;
             Op o{};
-            o.frame = f; o.predict = predict; o.wd.K = 0;
+            o.frame = f; o.predict = predict; o.K = 0;
             ops.push_back(o);
             continue;
         }
         // pop order = ascending landmark index (aruco_slam.h:85-88); "stationary" test against last frame's list (:192-198)
-        bool any_stationary = false;
+        FramePlan& fp = plans[f - p.first];
+        fp.n_markers = nM;
+        int n_stationary = 0;
         std::vector<aslam_ctx::HostLast> nlast(pop.size());
         for (size_t j = 0; j < pop.size(); j++) {
             const ObsRaw& o = ob[pop[j].second];
@@ -781,83 +787,108 @@ int finalize_pending(aslam_ctx* c) {
                     stationary = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2) < 0.01;     // NaN compares false
                     break;
                 }
-            any_stationary = any_stationary || stationary;
+            n_stationary += stationary ? 1 : 0;
             nlast[j].id = o.id;
             if (stationary) { nlast[j].z[0] = nlast[j].z[1] = nlast[j].z[2] = std::nan(""); }
             else { nlast[j].z[0] = o.x; nlast[j].z[1] = o.y; nlast[j].z[2] = o.th; }
+            fp.pop_idx.push_back(pop[j].first); fp.pop_det.push_back(pop[j].second); fp.pop_act.push_back(stationary ? 2 : 1);
+            if (!stationary) { fp.corr_idx.push_back(pop[j].first); fp.corr_det.push_back(pop[j].second); }
         }
         c->m_last.swap(nlast);
-        const int m = (int)pop.size();
-        const bool eligible = predict && n_new == 0 && !any_stationary && m >= 1 && m <= kWinM;
+        const int m = (int)fp.corr_idx.size();
+        const bool eligible = predict && n_new == 0 && m <= kWinCorrMax && (int)pop.size() <= 64 && m <= s_cap && m <= c->init.max_updates_per_frame;
         if (std::getenv("ASLAM_DEBUG_PLAN"))
-            std::fprintf(stderr, "plan frame %d: nM %d m %d new %d stationary %d predict %d eligible %d (window K %d)\n", f, nM, m, n_new, (int)any_stationary,
-                         (int)predict, (int)eligible, cur.K);
+            std::fprintf(stderr, "plan frame %d: nM %d m %d new %d stationary %d predict %d eligible %d (window K %d, |S| %zu)\n", f, nM, m, n_new, n_stationary,
+                         (int)predict, (int)eligible, w_K, w_S.size());
         if (!eligible) {
             close_window();
             Op o{};
-            o.frame = f; o.predict = predict; o.wd.K = 0;
+            o.frame = f; o.predict = predict; o.K = 0;
             ops.push_back(o);
             continue;
         }
-        bool same = cur.K > 0 && cur.K < kWinFrames && cur.m == m && f == cur.first_slot + cur.K;
-        for (int j = 0; j < m && same; j++) same = cur.li[j] == 3 + 3 * pop[j].first;
-        if (!same) {
+        // does the frame fit into the open window?  (its landmarks are ascending, like S)
+        std::vector<int> un;
+        if (w_K > 0) std::set_union(w_S.begin(), w_S.end(), fp.corr_idx.begin(), fp.corr_idx.end(), std::back_inserter(un));
+        if (w_K == 0 || w_K >= kWinFrames || (int)un.size() > s_cap || f != w_first + w_K) {
             close_window();
-            cur.first_slot = f; cur.K = 0; cur.m = m; cur.s = 3 + 3 * m;
-            for (int j = 0; j < m; j++) cur.li[j] = 3 + 3 * pop[j].first;
+            w_first = f; w_K = 0;
+            un = fp.corr_idx;
         }
-        for (int j = 0; j < m; j++) c->h_obs_idx[(size_t)f * kWinM + j] = (unsigned char)pop[j].second;
-        cur.K++;
+        w_S.swap(un);
+        w_K++;
     }
     close_window();
+    // the plan of every window frame in the device's format (positions within the final S of its window), one upload per batch
     bool any_window = false;
-    for (const Op& o : ops) any_window = any_window || o.wd.K > 0;
+    for (const Op& o : ops) {
+        if (o.K == 0) continue;
+        any_window = true;
+        for (int k = 0; k < o.K; k++) {
+            const FramePlan& fp = plans[o.frame + k - p.first];
+            WinFrame& wf = c->h_win_frames[o.frame + k];
+            wf.m = (int)fp.corr_idx.size(); wf.npop = (int)fp.pop_idx.size(); wf.n_markers = fp.n_markers; wf.pad = 0;
+            for (int a = 0; a < wf.m; a++) {
+                wf.cdet[a] = (unsigned char)fp.corr_det[a];
+                wf.cpos[a] = (unsigned char)(std::lower_bound(o.S.begin(), o.S.end(), fp.corr_idx[a]) - o.S.begin());
+            }
+            for (int i = 0; i < wf.npop; i++) {
+                wf.pdet[i] = (unsigned char)fp.pop_det[i]; wf.pact[i] = (unsigned char)fp.pop_act[i]; wf.pidx[i] = (short)fp.pop_idx[i];
+            }
+        }
+    }
     if (any_window) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_obs_idx + (size_t)p.first * kWinM, c->h_obs_idx + (size_t)p.first * kWinM, (size_t)p.count * kWinM,
+        HIP_TRY(c, hipMemcpyAsync(c->ekf.d_win_frames + p.first, c->h_win_frames + p.first, (size_t)p.count * sizeof(WinFrame),
                                   hipMemcpyHostToDevice, c->stream_ekf));
         HIP_TRY(c, hipEventRecord(c->ev_idx, c->stream_ekf));
         c->ev_idx_set = true;
     }
     for (const Op& o : ops) {
-        if (o.wd.K == 0) c->plan_stats[1]++;
-        else { c->plan_stats[0] += o.wd.K; c->plan_stats[2]++; }
+        if (o.K == 0) c->plan_stats[1]++;
+        else { c->plan_stats[0] += o.K; c->plan_stats[2]++; }
     }
     for (const Op& o : ops) {
-        if (o.wd.K == 0) {
+        if (o.K == 0) {
             const double* e = &c->enc_host[(size_t)3 * o.frame];
             int r = run_ekf_frame(c, o.frame, e[0], e[1], e[2], o.predict);
             if (r) return r;
         } else {
-            // One run = frames on the same landmarks.  Its chain is cut into pieces of kWinChainFrames frames on the EKF stream;
-            // the replay of each piece's log (scan) and the run's single pass over Sigma (flush) go to a second stream, so
-            // that only the last piece's scan and the flush are not hidden behind the chain.
+            // One window = K frames on the set S.  Its chain is cut into pieces of a few frames on the EKF stream; the replay of
+            // each piece's log (scan + Psi) and the window's single pass over Sigma (flush) go to a second stream, so that only
+            // the last piece's replay and the flush are not hidden behind the chain.
             hipStream_t sa = c->stream_ekf, sb = c->stream_win;
-            // The chain of the NEXT window waits for this run's last scan and the flush: the last piece is kept short (kWinLastPiece
-            // frames), so that the scan in front of the flush has little left to replay.
-            int piece = 0;
-            for (int k0 = 0, kn = 0; k0 < o.wd.K; k0 += kn, piece++) {
-                const int left = o.wd.K - k0;
+            WinDesc wd{};
+            wd.nS = (int)o.S.size();
+            wd.T = ekf_win_tiles(wd.nS);
+            for (int a = 0; a < wd.nS; a++) wd.li[a] = (short)(3 + 3 * o.S[a]);
+            // The chain of the NEXT window waits for this window's last replay and the flush: the last piece is kept short
+            // (kWinLastPiece frames), so that the replay in front of the flush has little left to do.
+            int piece = 0, log0 = 0;
+            for (int k0 = 0, kn = 0; k0 < o.K; k0 += kn, piece++) {
+                const int left = o.K - k0;
                 kn = std::min(c->win_piece, left);
                 if (kn == left && kn > kWinLastPiece) kn -= kWinLastPiece;
-                WinDesc sub = o.wd;
-                sub.first_slot = o.wd.first_slot + k0;
+                WinDesc sub = wd;
+                sub.first_slot = o.frame + k0;
                 sub.K = kn;
-                sub.cont = piece;                                  // index of the piece: the scan alternates between two accumulator sets
-                sub.log0 = k0;
+                sub.piece = piece;
+                sub.log0 = log0;
+                sub.last = k0 + kn == o.K ? 1 : 0;
+                int nsteps = 0;
+                for (int k = 0; k < kn; k++) nsteps += 1 + c->h_win_frames[sub.first_slot + k].m;
                 prof_begin(c, P_EKF_WIN_CHAIN, sa);
-                launch_ekf_win_chain(sa, c->ekf, c->sp, sub, c->d_obs, c->d_nmarkers, c->d_enc, c->d_obs_idx + (size_t)sub.first_slot * kWinM);
+                launch_ekf_win_chain(sa, c->ekf, c->sp, sub, c->d_obs, c->d_enc);
                 prof_end(c);
                 hipEvent_t ev = c->ev_win[c->ev_win_next++ & 15];
                 HIP_TRY(c, hipEventRecord(ev, sa));
                 HIP_TRY(c, hipStreamWaitEvent(sb, ev, 0));
                 prof_begin(c, P_EKF_WIN_SCAN, sb);
-                launch_ekf_win_scan(sb, c->ekf, sub);
+                launch_ekf_win_scan(sb, c->ekf, sub, nsteps);
                 prof_end(c);
+                log0 += nsteps;
             }
             prof_begin(c, P_EKF_WIN_FLUSH, sb);
-            WinDesc fwd = o.wd;
-            fwd.cont = piece - 1;                                  // the set the last scan piece wrote
-            launch_ekf_win_flush(sb, c->ekf, fwd);
+            launch_ekf_win_flush(sb, c->ekf, wd);
             prof_end(c);
             hipEvent_t ev = c->ev_win[c->ev_win_next++ & 15];
             HIP_TRY(c, hipEventRecord(ev, sb));

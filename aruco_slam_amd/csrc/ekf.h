@@ -28,14 +28,29 @@ struct MapRecord {                     // 104-byte landmark record gathered acro
     double S[9];
 };
 
-// ---- windowed EKF (ekf_window.hip): runs of frames that fuse the same landmarks --------------------------------------
-constexpr int kWinM = 20;              // landmarks per window frame at most (s = 3 + 3 m <= 63 fits 64 x 64 images)
+// ---- windowed EKF (ekf_window.hip): runs of frames whose fused landmarks stay inside one set S --------------------------
 constexpr int kWinFrames = 64;         // frames per window at most
-struct WinDesc {                       // one window (kernel argument)
-    int first_slot, K, m, s;           // slots first_slot .. first_slot + K - 1; s = 3 + 3 m
-    int cont, log0;                    // a run (frames on the same landmarks) is cut into chains of a few frames: cont = index of the
-                                       // piece within its run (0 = first; for the flush: of the LAST piece), log0 = frames already logged
-    int li[kWinM];                     // state offset 3 + 3 index of every landmark, ascending (= pop order, aruco_slam.h:85-88)
+constexpr int kWinPieceMax = 16;       // frames per chain piece at most (its step table lives in LDS)
+constexpr int kWinCorrMax = 63;        // corrections fused per window frame at most (one lane of the prepare wave each)
+constexpr int kWinSMax = 63;           // landmarks in a window's set S at most: 3 + 3 * 63 = 192 = 12 MFMA tiles
+constexpr int kWinHdr = 24;            // doubles of scalar header per logged step (after the 3 operand rows)
+struct WinFrame {                      // host-planned bookkeeping of one window frame (aruco_slam.cpp:92-95, 192-198, 423-435 replayed on the host)
+    int m;                             // corrections fused, in pop order = ascending landmark index (aruco_slam.h:85-88)
+    int npop;                          // popped observations: the m corrections + the "stationary" no-ops
+    int n_markers;                     // detections of the frame (statistics)
+    int pad;
+    unsigned char cdet[64];            // correction a: index of its detection in the frame's observation list
+    unsigned char cpos[64];            // ... and the position of its landmark in S (rows 3 + 3 pos .. 5 + 3 pos of the S block)
+    unsigned char pdet[64];            // popped observation i: detection index
+    unsigned char pact[64];            // ... 1 = update, 2 = stationary no-op
+    short pidx[64];                    // ... landmark index
+};
+struct WinDesc {                       // one chain piece / one window (kernel argument)
+    int first_slot, K;                 // slots first_slot .. first_slot + K - 1
+    int nS, T;                         // landmarks in S; MFMA tiles per side: SP = 16 T >= s = 3 + 3 nS  (T = 4, 8 or 12)
+    int piece, log0;                   // index of the piece within its window; steps logged by the earlier pieces
+    int last, pad;                     // 1 = the window's last piece: the last frame's pop list / last-observation list are left behind
+    short li[kWinSMax + 1];            // state offset 3 + 3 index of every landmark of S, ascending
 };
 
 struct EkfState {
@@ -55,14 +70,17 @@ struct EkfState {
     double *d_V, *d_Wt, *d_T;          // 3m x ld each, row k contiguous
     double *d_Sv, *d_Sw, *d_alpha, *d_gamma, *d_G, *d_g;
     MapRecord* d_maprec;
-    double* d_win_log;                 // per window frame: G, W, V images, g, H3, Jacobians (ekf_window.hip)
-    double* d_win_small;               // Lambda, Gamma, Psi, P_K images and psi
+    double* d_win_log;                 // per window step: operand rows -K^T (3 x SP) + header (ekf_window.hip)
+    double* d_win_tlog;                // per window step: t = H Lambda and u = S^-1 t (4 x SP each, 4th row zero)
+    double* d_win_small;               // P_K, Lambda, Psi images (SP x SP) and psi
     int* d_win_sidx;                   // per state index: position in S or -1
+    WinFrame* d_win_frames;            // per staged slot: the host's plan of the frame
+    int win_sp_max, win_steps_max;     // capacity: largest SP and most steps (frames + corrections) per window
     int* d_slot_stat;                  // per staged slot, written by k_ekf_plan: detections, augments, fused updates, stationary no-ops
     int max_slots;
 };
 
-hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots);
+hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots, int max_updates_per_frame);
 void ekf_free(EkfState& E);
 void launch_ekf_predict_only(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt);
 void launch_ekf_plan(hipStream_t st, const EkfState& E, const SlamParams& sp, double wl, double wr, double dt, int do_predict,
@@ -72,17 +90,15 @@ void launch_ekf_apply(hipStream_t st, const EkfState& E);
 int ekf_fast_max_updates();
 int ekf_mid_max_updates();
 void launch_ekf_mid64(hipStream_t st, const EkfState& E);
-void launch_ekf_update_mfma(hipStream_t st, const EkfState& E);
+void launch_ekf_update_mfma(hipStream_t st, const EkfState& E, int depth = -1);   // depth >= 0: rows of d_T / d_Wt to contract instead of 3 * *d_m
 void launch_ekf_gather(hipStream_t st, const EkfState& E);
 void launch_ekf_small(hipStream_t st, const EkfState& E);
 void launch_ekf_T(hipStream_t st, const EkfState& E);
 void launch_ekf_export_map(hipStream_t st, const EkfState& E);
-size_t ekf_win_log_doubles();
-size_t ekf_win_small_doubles();
-// obs / n_markers / enc: the context's per-slot arrays; d_obs_idx: K x kWinM bytes, detection index of the j-th popped observation
-void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs,
-                          const unsigned* n_markers, const double* enc, const unsigned char* d_obs_idx);
-void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd);
-void launch_ekf_win_flush(hipStream_t st, const EkfState& E, const WinDesc& wd);
+int ekf_win_tiles(int nS);             // T for a set of nS landmarks (4, 8 or 12)
+// obs / enc: the context's per-slot arrays
+void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc);
+void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd, int nsteps);      // + Psi accumulation of the piece
+void launch_ekf_win_flush(hipStream_t st, const EkfState& E, const WinDesc& wd);                 // thin products, Sigma pass, rows / columns of S
 
 } // namespace aslam

@@ -15,6 +15,7 @@
 #include "ekf.h"
 #include "ekf_dev.h"
 #include <cmath>
+#include <algorithm>
 
 namespace aslam {
 
@@ -1188,13 +1189,12 @@ constexpr int MUR = 64;                  // rows of Sigma per workgroup
 // loaded straight into the accumulators before the depth loop (its latency hides behind the first chunks) and the product
 // is subtracted by negating one operand: the epilogue is a pure store.
 template <int WCT>
-__global__ __launch_bounds__(128) void k_ekf_update_mfma(EkfState E) {
+__global__ __launch_bounds__(128) void k_ekf_update_mfma(EkfState E, int depth) {
     constexpr int MUC = 2 * 16 * WCT;                              // columns per workgroup
     __shared__ double sT[2][MUK][MUC];
     __shared__ double sW[2][MUK][MUR];
-    const int m = *E.d_m;
-    if (m <= 0) return;
-    const int n3 = 3 * m;
+    const int n3 = depth >= 0 ? depth : 3 * (*E.d_m);             // rows of d_T / d_Wt contracted (the window flush passes its own)
+    if (n3 <= 0) return;
     const int N = 3 + 3 * (*E.d_L);
     const int ld = E.ld;
     const int cb0 = blockIdx.y * MUC, rb0 = blockIdx.x * MUR;     // workgroup tile: columns cb0.., rows rb0.. of Sigma
@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(256) void k_ekf_export_map(EkfState E) {
 // ---- host side -------------------------------------------------------------------------------------------
 template <class T> static hipError_t dalloc(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)); }
 
-hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots) {
+hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots, int max_updates_per_frame) {
     E = EkfState{};
     E.max_landmarks = max_landmarks;
     E.max_slots = max_slots;
@@ -1328,9 +1328,14 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots) {
     A(dalloc(&E.d_G, n3 * n3));
     A(dalloc(&E.d_g, n3));
     A(dalloc(&E.d_maprec, (size_t)max_landmarks));
-    A(dalloc(&E.d_win_log, ekf_win_log_doubles()));
-    A(dalloc(&E.d_win_small, ekf_win_small_doubles()));
+    // windowed EKF: contexts configured for <= 24 corrections per frame keep sets of <= 41 landmarks (SP <= 128)
+    E.win_sp_max = max_updates_per_frame <= 24 ? 128 : 192;
+    E.win_steps_max = kWinFrames * (1 + std::min(max_updates_per_frame, kWinCorrMax));
+    A(dalloc(&E.d_win_log, (size_t)E.win_steps_max * (3 * E.win_sp_max + kWinHdr) + 512));
+    A(dalloc(&E.d_win_tlog, (size_t)E.win_steps_max * 8 * E.win_sp_max));
+    A(dalloc(&E.d_win_small, (size_t)3 * E.win_sp_max * E.win_sp_max + E.win_sp_max));
     A(dalloc(&E.d_win_sidx, ld));
+    A(dalloc(&E.d_win_frames, (size_t)max_slots));
     A(dalloc(&E.d_slot_stat, (size_t)4 * max_slots));
     A(hipMemset(E.d_slot_stat, 0, (size_t)4 * max_slots * sizeof(int)));
     // ArucoSlam::ArucoSlam (aruco_slam.cpp:13-18): mu = 0 (3), sigma = 0 (3x3), empty map
@@ -1350,7 +1355,7 @@ void ekf_free(EkfState& E) {
     hipFree(E.d_mu); hipFree(E.d_sigma); hipFree(E.d_L); hipFree(E.d_id2idx); hipFree(E.d_idx2id); hipFree(E.d_last); hipFree(E.d_lastNext);
     hipFree(E.d_nlast); hipFree(E.d_pop); hipFree(E.d_npop); hipFree(E.d_upd); hipFree(E.d_m); hipFree(E.d_V); hipFree(E.d_Wt);
     hipFree(E.d_T); hipFree(E.d_Sv); hipFree(E.d_Sw); hipFree(E.d_alpha); hipFree(E.d_gamma); hipFree(E.d_G); hipFree(E.d_g);
-    hipFree(E.d_maprec); hipFree(E.d_slot_stat); hipFree(E.d_win_log); hipFree(E.d_win_small); hipFree(E.d_win_sidx);
+    hipFree(E.d_maprec); hipFree(E.d_slot_stat); hipFree(E.d_win_log); hipFree(E.d_win_tlog); hipFree(E.d_win_small); hipFree(E.d_win_sidx); hipFree(E.d_win_frames);
     E = EkfState{};
 }
 
@@ -1384,13 +1389,13 @@ void launch_ekf_mid64(hipStream_t st, const EkfState& E) {
     const int ncg = (E.ld + M64T - 1) / M64T;
     hipLaunchKernelGGL(k_ekf_mid64, dim3(1 + ncg * 16), dim3(M64T), 0, st, E);
 }
-void launch_ekf_update_mfma(hipStream_t st, const EkfState& E) {
+void launch_ekf_update_mfma(hipStream_t st, const EkfState& E, int depth) {
     // the narrowest tile whose workgroups all fit on the device at once (256 CUs x 4); N_max stands in for the current N
     const int rt = (E.ld + MUR - 1) / MUR;
     if (rt * ((E.ld + 127) / 128) <= 1024 || rt * ((E.ld + 159) / 160) > 1024)
-        hipLaunchKernelGGL(k_ekf_update_mfma<4>, dim3(rt, (E.ld + 127) / 128), dim3(128), 0, st, E);
+        hipLaunchKernelGGL(k_ekf_update_mfma<4>, dim3(rt, (E.ld + 127) / 128), dim3(128), 0, st, E, depth);
     else
-        hipLaunchKernelGGL(k_ekf_update_mfma<5>, dim3(rt, (E.ld + 159) / 160), dim3(128), 0, st, E);
+        hipLaunchKernelGGL(k_ekf_update_mfma<5>, dim3(rt, (E.ld + 159) / 160), dim3(128), 0, st, E, depth);
 }
 void launch_ekf_export_map(hipStream_t st, const EkfState& E) {
     hipLaunchKernelGGL(k_ekf_export_map, dim3((E.max_landmarks + 255) / 256), dim3(256), 0, st, E);

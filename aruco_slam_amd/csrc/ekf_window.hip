@@ -1,30 +1,37 @@
-// Windowed EKF: a run of K consecutive frames that fuse the SAME m landmarks (no new landmark, no "stationary" no-op,
-// m <= kWinM) is processed without streaming the N x N covariance once per frame.
+// Windowed EKF: a run of consecutive frames whose fused landmarks all lie in one set S (no new landmark; at most kWinSMax
+// landmarks in the union) is processed on the S x S block of the covariance only; the rest of Sigma follows ONCE per window.
 //
-// Split the state into S (robot pose + the m observed landmarks, s = 3 + 3m <= 63) and R (everything else):
-//     Sigma = [ P  Y ]      P = Sigma[S,S]   Y = Sigma[S,R]
-//             [ X  Z ]      X = Sigma[R,S]   Z = Sigma[R,R]
-// Every predict (aruco_slam.cpp:21-74: D = blkdiag(H3, I) on S, process noise on the pose block) and every correction
-// (aruco_slam.cpp:108-207 fused per frame: H = [H_S 0], G = (H_S P' H_S^T + R)^-1, W = P' H_S^T, V = H_S P') touches R only
-// through X and Y, linearly:
-//     P+ = P' - W G V                     Y+ = (D Y) - W G (H_S D Y)                 X+ = (X D^T) - (X D^T H_S^T) G V
-//     Z+ = Z - (X D^T H_S^T) G (H_S D Y)  mu_R+ = mu_R + (X D^T H_S^T) g
-// hence, over the whole window, with s x s accumulators Lambda, Gamma, Psi and a vector psi
-//     Y_K = Lambda Y_0      X_K = X_0 Gamma      Z_K = Z_0 - X_0 Psi Y_0      mu_R,K = mu_R,0 + X_0 psi
-//     Lambda+ = D Lambda - W G B       Gamma+ = Gamma D^T - A G V       Psi+ = Psi + A G B      psi+ = psi + A g
-//     with  B = H_S D Lambda  (3m x s),   A = Gamma D^T H_S^T  (s x 3m).
-// This is the reference's arithmetic regrouped: the same identity that fuses one frame's M corrections (ekf.hip) applied across
-// frames.  Nothing is approximated; the one property used beyond the identity is that the S x S block P is symmetric to
-// rounding (it is in the reference: aruco_slam.cpp:73, 204 keep Sigma = Sigma^T up to the last bit or two), so that inside the
-// chain kernel V = H_S P' is read as W^T and the innovation matrix A = H_S W + R is treated as symmetric.  X / Gamma and
-// Y / Lambda are NOT assumed to be transposes of each other.  Three kernels per window:
-//   k_ekf_win_chain   one workgroup runs the K frames on P and mu_S held in LDS (predict, records, innovation matrix,
-//                     block Gauss-Jordan, P update on the f64 matrix cores) and logs G, W, g, H3 and the Jacobians of every
-//                     frame; further workgroups copy X_0 (columns S of Sigma) and Y_0 (rows S) aside meanwhile;
-//   k_ekf_win_scan    4 x 4 workgroups replay the log: workgroup (i, j) carries 16 columns of Lambda, 16 rows of Gamma and
-//                     the 16 x 16 block of Psi they determine (columns of Lambda and rows of Gamma evolve independently);
-//   k_ekf_win_flush   one workgroup per 64 x 64 tile of Sigma: Z tile -= X_0 (Psi Y_0), rows / columns of S replaced by
-//                     Lambda Y_0 / X_0 Gamma / P_K, mu_R += X_0 psi - the ONE pass over Sigma per window.
+// Split the state into S (robot pose + the landmarks of the set, s = 3 + 3 nS, padded to SP = 16 T) and R (everything else):
+//     Sigma = [ P   Y ]      P = Sigma[S,S]   Y = Sigma[S,R]   Z = Sigma[R,R]      (Sigma is symmetric to rounding: aruco_slam.cpp:73, 204)
+//             [ Y^T Z ]
+// The reference's filter is sequential: one predict per encoder sample (aruco_slam.cpp:21-74: Sigma <- D Sigma D^T + Q, D = identity
+// except its pose block) and, per popped observation j of a frame, K_j = Sigma H_j^T (H_j Sigma H_j^T + R_j)^-1 with the LIVE Sigma
+// and the innovation at the frame's FROZEN mean, mu += K_j ze_j, Sigma <- (I - K_j H_j) Sigma (aruco_slam.cpp:88, 108-207).  H_j has
+// only the pose block and the block of landmark j, so restricted to S every one of these steps is a rank-3 (predict: rank-4)
+// correction of P,
+//     correction:  c = H_j P (3 x s),  S_j = c H_j^T + R_j,  Kt = S_j^-1 c (= K_j^T),  P <- P - Kt^T c,  mu_S += Kt^T ze_j
+//     predict:     P <- P + u r2 + (r2^T + P22 u) u^T + Q     (u = the third column of D - I, r2 = row 2 of P; Q = F Qk F^T has rank 2)
+// and touches R only linearly through Y:  Y <- D Y,  Y <- Y - Kt^T (H_j Y),  Z <- Z - (H_j Y)^T S_j^-1 (H_j Y),
+// mu_R <- mu_R + (H_j Y)^T S_j^-1 ze_j.  Hence, over the whole window, with an s x s accumulator Lambda (= I at the start),
+//     Y_K = Lambda Y_0      Z_K = Z_0 - Y_0^T Psi Y_0      mu_R,K = mu_R,0 + Y_0^T psi
+//     per step:  t = H_j Lambda,  u = S_j^-1 t,  Lambda <- Lambda - Kt^T t  (predict: Lambda <- D Lambda),  Psi += t^T u,  psi += t^T S_j^-1 ze_j
+// This is the reference's own arithmetic, step for step, on the rows and columns it can change; nothing is approximated.  The one
+// property used is the symmetry of Sigma (H P read as (P H^T)^T, X = Y^T).  Frames of a window may fuse ANY subset of S, in the
+// reference's pop order (ascending landmark index = ascending position in S), and may drop "stationary" observations
+// (aruco_slam.cpp:192-198: a no-op): a window ends only when a frame brings a landmark that does not fit into S, or a new one.
+//
+// Kernels (per window; a window's frames are cut into chain pieces of a few frames so that the replay runs beside the chain):
+//   k_ekf_win_chain   ONE workgroup walks the steps of a piece.  P lives in the f64 matrix-core accumulators of the worker waves for
+//                     the whole piece (wave w: RW tile rows of T 16 x 16 tiles); a step is one v_mfma_f64_16x16x4_f64 per tile
+//                     (depth 3 or 4).  A separate "prepare" wave (lane = column) runs one step AHEAD: the workers publish the six
+//                     rows (pose + landmark) of step j + 2 as they stand after step j, the prepare wave applies step j + 1's correction
+//                     to them itself from the operands it still holds (v_readlane, no LDS), forms c, S, S^-1, Kt and hands the
+//                     operands to the workers: one barrier per step.  It also logs -Kt, S^-1, ze and the Jacobian scalars;
+//                     further workgroups of the first piece copy Y_0 (rows S of Sigma) aside meanwhile.
+//   k_ekf_win_scan    SP / 16 workgroups replay the log, each on its own 16 columns of Lambda (all rows; in LDS) and its part
+//                     of psi, and log t and u;  k_ekf_win_psi adds the piece's t^T u to Psi on the matrix cores.
+//   k_ekf_win_thin    per 64 columns of Sigma: U = Psi Y_0 and Y_K = Lambda Y_0 (SP x 64, matrix cores), mu_R += Y_0^T psi;
+//   k_ekf_update_mfma (ekf.hip) Sigma -= Y_0^T U: the ONE pass over Sigma per window;  k_ekf_win_fix writes rows / columns S and P_K.
 #include "common.h"
 #include "ekf.h"
 #include "ekf_dev.h"
@@ -32,716 +39,610 @@
 
 namespace aslam {
 
-constexpr int WS = 66;                        // row stride (doubles) of a 64 x 64 image: conflict-free MFMA A-operand reads from LDS
-constexpr int WIMG = 64 * WS;                 // doubles per image
-constexpr int WLOG_G = 0, WLOG_W = WIMG, WLOG_g = 2 * WIMG, WLOG_H3 = WLOG_g + 64, WLOG_HREC = WLOG_H3 + 16;
-constexpr int WLOG_STRIDE = WLOG_HREC + kWinM * 18;     // doubles per logged frame
-// layout of d_win_small: TWO sets of the scan's accumulators (Lambda | Gamma | Psi | psi), then P.  A continuation piece of the scan
-// reads the set the previous piece wrote and writes the other one: its 4 x 4 workgroups share Lambda's column blocks, Gamma's row
-// blocks and psi, and a workgroup that finishes early must not overwrite what a workgroup that starts late still has to read.
-constexpr int WSM_SET = 3 * WIMG + 64;
-constexpr int WSM_LAM = 0, WSM_GAM = WIMG, WSM_PSI = 2 * WIMG, WSM_psi = 3 * WIMG, WSM_P = 2 * WSM_SET;
-constexpr int WCT = 512;                      // threads of the chain workgroup
+constexpr int WBW = 16;                       // columns of Lambda per scan workgroup
 
-// development aid (make FLAGS+=-DASLAM_WIN_STAMPS): cycle stamps of the chain's phases, printed for one frame
-#ifdef ASLAM_WIN_STAMPS
-#define WIN_STAMP(i) do { if (tid == 0 && k == 3) stamps[i] = clock64(); } while (0)
-#ifdef ASLAM_GJ_STAMPS
-#define GJ_STAMP(i) do { if ((tid & 63) == 0 && k == 3 && j == 5) gst[i] = clock64(); } while (0)
-#else
-#define GJ_STAMP(i) do { } while (0)
-#endif
-#else
-#define WIN_STAMP(i) do { } while (0)
-#define GJ_STAMP(i) do { } while (0)
-#endif
+__host__ __device__ inline int win_log_stride(int T) { return 3 * 16 * T + kWinHdr; }
+__host__ __device__ inline int win_tlog_stride(int T) { return 8 * 16 * T; }
+// header of a logged step (doubles after the three operand rows)
+enum { WH_TYPE = 0, WH_POS = 1, WH_SI = 2, WH_ZE = 11, WH_C = 14, WH_S = 15, WH_G02 = 16, WH_G12 = 17, WH_A = 18, WH_B = 19 };
+// d_win_small: images of the window, each SPm x SPm at most (SPm = E.win_sp_max), stored with the window's own row stride SP
+__host__ __device__ inline size_t wsm_P(int) { return 0; }
+__host__ __device__ inline size_t wsm_LAM(int SPm) { return (size_t)SPm * SPm; }
+__host__ __device__ inline size_t wsm_PSI(int SPm) { return (size_t)2 * SPm * SPm; }
+__host__ __device__ inline size_t wsm_psi(int SPm) { return (size_t)3 * SPm * SPm; }
 
-size_t ekf_win_log_doubles() { return (size_t)WLOG_STRIDE * kWinFrames + 512; }   // + slack: the scan stages whole 16-byte x 256-thread passes
-size_t ekf_win_small_doubles() { return (size_t)2 * WSM_SET + WIMG; }
-
-// Gauss-Jordan image layout: element (r, c) of the 64 x 64 image.  Column-major with the rows of every 16-row tile regrouped so
-// that the four rows one lane holds of an MFMA accumulator tile (r = 16 g + lk + 4 reg) are neighbours: 16-byte LDS accesses.
-__device__ __forceinline__ int gpix(int r, int c) { return c * WS + (r & 48) + 4 * (r & 3) + ((r >> 2) & 3); }
-
-// rows p .. p + 2 of the image leave the accumulators of the working wave(s) that own them (row r = 16 g + lk + 4 reg of tile
-// row g): lanes with lk == r & 3 write their register reg = (r >> 2) & 3 of each of the four column tiles.  The register number
-// must be static (a select chain over the accumulators costs more than the rest of the step): one instance per p mod 16.
-template <int P16> __device__ __forceinline__ void gj_publish_rows_at(const v4d (&ga)[4], int p, int gw, int lk, int li, double* rows) {
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-        const int rl = (P16 + q) & 15;
-        if (gw == ((p + q) >> 4) && lk == (rl & 3)) {
-            double* d = rows + q * 64 + li;
-            d[0] = ga[0][rl >> 2]; d[16] = ga[1][rl >> 2]; d[32] = ga[2][rl >> 2]; d[48] = ga[3][rl >> 2];
-        }
-    }
-}
-__device__ __forceinline__ void gj_publish_rows(const v4d (&ga)[4], int p, int gw, int lk, int li, double* rows) {
-    switch (p & 15) {
-#define ASLAM_GJ_CASE(i) case i: gj_publish_rows_at<i>(ga, p, gw, lk, li, rows); break;
-        ASLAM_GJ_CASE(0) ASLAM_GJ_CASE(1) ASLAM_GJ_CASE(2) ASLAM_GJ_CASE(3) ASLAM_GJ_CASE(4) ASLAM_GJ_CASE(5) ASLAM_GJ_CASE(6) ASLAM_GJ_CASE(7)
-        ASLAM_GJ_CASE(8) ASLAM_GJ_CASE(9) ASLAM_GJ_CASE(10) ASLAM_GJ_CASE(11) ASLAM_GJ_CASE(12) ASLAM_GJ_CASE(13) ASLAM_GJ_CASE(14) ASLAM_GJ_CASE(15)
-#undef ASLAM_GJ_CASE
-    }
-}
+int ekf_win_tiles(int nS) { return nS <= 20 ? 4 : nS <= 41 ? 8 : 12; }
 
 __device__ __forceinline__ int win_state_index(const WinDesc& wd, int p) {      // state offset of position p of S
     return p < 3 ? p : wd.li[(p - 3) / 3] + (p - 3) % 3;
 }
 
+// value of element `idx` (0 .. 64 NC - 1) of a per-lane array v[NC] (element idx lives in lane idx & 63 of v[idx >> 6]); idx is
+// wave-uniform.  Every lane of the wave must call it.
+template <int NC> __device__ __forceinline__ double bcast_at(const double (&v)[NC], int idx) {
+    const int ch = idx >> 6, ln = idx & 63;
+    double r = ASLAM_WAVE_BCAST(v[0], ln);
+    if (NC > 1) { const double r1 = ASLAM_WAVE_BCAST(v[NC > 1 ? 1 : 0], ln); r = ch == 1 ? r1 : r; }
+    if (NC > 2) { const double r2 = ASLAM_WAVE_BCAST(v[NC > 2 ? 2 : 0], ln); r = ch == 2 ? r2 : r; }
+    return r;
+}
+
+// Rows p .. p + 2 of the image leave the accumulators of the worker wave(s) that own them (row r = 16 g + lk + 4 reg of tile row
+// g): lanes with lk == r & 3 write their register reg = (r >> 2) & 3 of each of the T column tiles.  The register number must
+// be static (a select chain over the accumulators costs more than the rest of the step): one instance per p mod 16.
+template <int P16, int T, int RW>
+__device__ __forceinline__ void win_publish_at(const v4d (&acc)[RW][T], int p, int wv, int lk, int li, double* rows, int spp) {
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const int rl = (P16 + q) & 15;
+        const int g = (p + q) >> 4;
+        double* d = rows + q * spp + li;
+#pragma unroll
+        for (int rr = 0; rr < RW; rr++)
+            if (g == wv * RW + rr && lk == (rl & 3)) {
+#pragma unroll
+                for (int t = 0; t < T; t++) d[16 * t] = acc[rr][t][rl >> 2];
+            }
+    }
+}
+template <int T, int RW>
+__device__ __forceinline__ void win_publish(const v4d (&acc)[RW][T], int p, int wv, int lk, int li, double* rows, int spp) {
+    switch (p & 15) {
+#define ASLAM_WP_CASE(i) case i: win_publish_at<i, T, RW>(acc, p, wv, lk, li, rows, spp); break;
+        ASLAM_WP_CASE(0) ASLAM_WP_CASE(1) ASLAM_WP_CASE(2) ASLAM_WP_CASE(3) ASLAM_WP_CASE(4) ASLAM_WP_CASE(5) ASLAM_WP_CASE(6) ASLAM_WP_CASE(7)
+        ASLAM_WP_CASE(8) ASLAM_WP_CASE(9) ASLAM_WP_CASE(10) ASLAM_WP_CASE(11) ASLAM_WP_CASE(12) ASLAM_WP_CASE(13) ASLAM_WP_CASE(14) ASLAM_WP_CASE(15)
+#undef ASLAM_WP_CASE
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WCT) void k_ekf_win_chain(EkfState E, SlamParams sp, WinDesc wd, const ObsRaw* __restrict__ obs,
-                                                      const unsigned* __restrict__ n_markers, const double* __restrict__ enc,
-                                                      const unsigned char* __restrict__ obs_idx) {
-    __shared__ __align__(16) double sP[WIMG];
-    __shared__ __align__(16) double sW[WIMG];
-    __shared__ __align__(16) double sV[WIMG];          // J = G V
-    __shared__ __align__(16) double sG[WIMG];
-    __shared__ double sMu[64], sZe[64], sNu[64];
-    __shared__ double sHr[kWinM][9], sHl[kWinM][9], sRd[kWinM][3];
-    __shared__ double sH3[9], sQ[9], sPose[5];
-    __shared__ double sGY[2][4][WS];                   // Gauss-Jordan: a step's B operand Y~ (3 x 64, 4th depth row zero), double buffered
-    __shared__ double sRow[2][4][64];                  // ... and its pivot rows (the column operand by symmetry; 4th row zero)
-    __shared__ double sPub[2][3][64];                  // rows of the pivot after next, as published by the workers that own them
-    __shared__ int sS[64];
+// T tiles per side, RW tile rows per worker wave: T / RW worker waves + 1 prepare wave.
+template <int T, int RW>
+__global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E, SlamParams sp, WinDesc wd, const ObsRaw* __restrict__ obs,
+                                                                    const double* __restrict__ enc) {
+    constexpr int SP = 16 * T, SPP = SP + 16, NC = SP / 64;       // SPP: operand rows lk and lk + 1 fall on opposite halves of the bank row
+    constexpr int NWK = T / RW, NT = (NWK + 1) * 64;
+    constexpr int NSMAX = kWinPieceMax * 64;
+    __shared__ __align__(16) double sA[2][4][SPP];                 // a step's A operand rows  Aop[k][row]   (P += Aop^T Bop)
+    __shared__ __align__(16) double sB[2][4][SPP];                 // ... and B operand rows   Bop[k][column]
+    __shared__ __align__(16) double sPub[2][6][SPP];               // rows 0..2 (pose) and the landmark rows of the step after next
+    __shared__ double sMu[SPP];                                    // prepare wave's scratch: mu_S by position
+    __shared__ int sS[SP];
+    __shared__ unsigned char sPos[NSMAX], sIdx[NSMAX], sFrm[NSMAX];   // per step: landmark position (255 = predict), correction index, frame
+    __shared__ int sOff[kWinPieceMax + 1];
     const int tid = threadIdx.x;
-    const int m = wd.m, s = wd.s, n3 = 3 * m;
+    const int nS = wd.nS, s = 3 + 3 * nS;
     const int ld = E.ld;
+    const WinFrame* __restrict__ frames = E.d_win_frames;
 
     if (blockIdx.x > 0) {
-        if (wd.cont) return;                                       // a run's later chains: X_0, Y_0 are those of its first one
-        // ---- X_0^T (row p = column S_p of Sigma) -> d_Wt, Y_0 (row p = row S_p of Sigma) -> d_V, S-position table ----
+        // ---- further workgroups of a window's first piece: Y_0 (row p = row S_p of Sigma = its column S_p) -> d_Wt, position table ----
         const int N = 3 + 3 * (*E.d_L);
-        for (int t = (blockIdx.x - 1) * WCT + tid; t < N; t += (gridDim.x - 1) * WCT) {
+        for (int t = (blockIdx.x - 1) * NT + tid; t < N; t += (gridDim.x - 1) * NT) {
             int pos = -1;
             if (t < 3) pos = t;
             else {
                 const int base = (t - 3) / 3 * 3 + 3;
-                for (int a = 0; a < m; a++) if (wd.li[a] == base) pos = 3 + 3 * a + (t - base);
+                for (int a = 0; a < nS; a++) if (wd.li[a] == base) pos = 3 + 3 * a + (t - base);
             }
             E.d_win_sidx[t] = pos;
-            for (int p = 0; p < s; p++) {
-                const int Sp = win_state_index(wd, p);
-                E.d_Wt[(size_t)p * ld + t] = E.d_sigma[(size_t)Sp * ld + t];
-                E.d_V[(size_t)p * ld + t] = E.d_sigma[(size_t)t * ld + Sp];
-            }
+            for (int p = 0; p < SP; p++) E.d_Wt[(size_t)p * ld + t] = p < s ? E.d_sigma[(size_t)win_state_index(wd, p) * ld + t] : 0.0;
         }
         return;
     }
 
-    // ---- workgroup 0: P = Sigma[S,S] and mu_S into LDS (zero padded to 64) ----
-    if (tid < 64) {
-        sS[tid] = tid < s ? win_state_index(wd, tid) : 0; sMu[tid] = 0.0; sZe[tid] = 0.0; sNu[tid] = 0.0;
-        sGY[0][3][tid] = 0.0; sGY[1][3][tid] = 0.0; sRow[0][3][tid] = 0.0; sRow[1][3][tid] = 0.0;
-    }
-    for (int e = tid; e < WIMG; e += WCT) { sP[e] = 0.0; sW[e] = 0.0; sV[e] = 0.0; sG[e] = 0.0; }
-    __syncthreads();
-    if (tid < s) sMu[tid] = E.d_mu[sS[tid]];
-    if (wd.cont) {                                                 // the run goes on: P as the previous chain left it
-        for (int e = tid; e < WIMG; e += WCT) sP[e] = E.d_win_small[WSM_P + e];
-    } else {
-        for (int e = tid; e < s * s; e += WCT) {
-            const int q = e / s, p = e - q * s;                    // column q, row p: consecutive threads walk down a column
-            sP[p * WS + q] = E.d_sigma[(size_t)sS[q] * ld + sS[p]];
-        }
-    }
+    // ---- workgroup 0 ----
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const int bj = tid % m, bi = tid / m;                          // Gauss-Jordan block owned by this thread
-    const bool act = bi < m;
-    // prefetch of the first frame's inputs
-    ObsRaw myObs{};
-    if (tid < m) myObs = obs[(size_t)wd.first_slot * kMarkerMax + obs_idx[tid]];
-    double e_wl = 0, e_wr = 0, e_dt = 0;
-    if (tid == 0) { const double* e = enc + (size_t)3 * wd.first_slot; e_wl = e[0]; e_wr = e[1]; e_dt = e[2]; }
+    for (int e = tid; e < SP; e += NT) sS[e] = e < s ? win_state_index(wd, e) : 0;
+    for (int e = tid; e < 2 * 4 * SPP; e += NT) { (&sA[0][0][0])[e] = 0.0; (&sB[0][0][0])[e] = 0.0; }
+    for (int e = tid; e < 2 * 6 * SPP; e += NT) (&sPub[0][0][0])[e] = 0.0;
+    if (tid == 0) {
+        int o = 0;
+        for (int k = 0; k < wd.K; k++) { sOff[k] = o; o += 1 + frames[wd.first_slot + k].m; }
+        sOff[wd.K] = o;
+    }
+    __syncthreads();
+    const int NS = sOff[wd.K];                                    // steps of the piece: per frame one predict + m corrections
+    for (int k = 0; k < wd.K; k++) {
+        const WinFrame& fr = frames[wd.first_slot + k];
+        for (int a = tid; a <= fr.m; a += NT) {
+            const int st = sOff[k] + a;
+            sPos[st] = a == 0 ? 255 : fr.cpos[a - 1];
+            sIdx[st] = a == 0 ? 0 : (unsigned char)(a - 1);
+            sFrm[st] = (unsigned char)k;
+        }
+    }
     __syncthreads();
 
-#ifdef ASLAM_WIN_STAMPS
-    long long stamps[12] = {0};
-    long long gst[10] = {0};
-#endif
-    for (int k = 0; k < wd.K; k++) {
-        const int slot = wd.first_slot + k;
-        double* log = E.d_win_log + (size_t)(wd.log0 + k) * WLOG_STRIDE;
-        WIN_STAMP(0);
-        // ---- 1. predict (aruco_slam.cpp:35-73): pose, H3, Qk ----
-        if (tid == 0) {
-            const double delta_sl = sp.kl * (e_dt * e_wl), delta_sr = sp.kr * (e_dt * e_wr);
-            const double delta_theta = (delta_sr - delta_sl) / (2 * sp.b);
-            const double delta_s = 0.5 * (delta_sr + delta_sl);
-            const double m0 = sMu[0], m1 = sMu[1], m2 = sMu[2];
-            double c, sn;
-            sincos(m2 + 0.5 * delta_theta, &sn, &c);
-            double th = m2 + delta_theta;
-            wrap1(th);
-            sMu[0] = m0 + delta_s * c; sMu[1] = m1 + delta_s * sn; sMu[2] = th;
-            sH3[0] = 1.0; sH3[1] = 0.0; sH3[2] = -delta_s * sn;
-            sH3[3] = 0.0; sH3[4] = 1.0; sH3[5] = delta_s * c;
-            sH3[6] = 0.0; sH3[7] = 0.0; sH3[8] = 1.0;
-            const double f = 0.5 * sp.kl * e_dt;                    // kl for BOTH wheels (quirk Q7)
-            const double wkh[6] = {f * c, f * c, f * sn, f * sn, f * (1 / sp.b), f * (-1 / sp.b)};
-            const double su0 = sp.Q_k * fabs(e_wl), su1 = sp.Q_k * fabs(e_wr);
-            for (int i = 0; i < 3; i++)
-                for (int j = 0; j < 3; j++) sQ[i * 3 + j] = wkh[i * 2] * su0 * wkh[j * 2] + wkh[i * 2 + 1] * su1 * wkh[j * 2 + 1];
-            sPose[0] = sMu[0]; sPose[1] = sMu[1]; sPose[2] = th;
-            sincos(th, &sPose[3], &sPose[4]);
-            for (int i = 0; i < 9; i++) log[WLOG_H3 + i] = sH3[i];
-        }
-        ASLAM_LDS_BARRIER();
-        if (tid < s) {                                              // rows 0..2 <- H3 * rows 0..2 (every column)
-            const double a = sP[tid], b = sP[WS + tid], c = sP[2 * WS + tid];
-            sP[tid] = sH3[0] * a + sH3[1] * b + sH3[2] * c;
-            sP[WS + tid] = sH3[3] * a + sH3[4] * b + sH3[5] * c;
-            sP[2 * WS + tid] = sH3[6] * a + sH3[7] * b + sH3[8] * c;
-        }
-        ASLAM_LDS_BARRIER();
-        if (tid < s) {                                              // columns 0..2 <- columns 0..2 * H3^T (every row), + Qk on the pose block
-            double* row = sP + tid * WS;
-            const double a = row[0], b = row[1], c = row[2];
-            double v0 = a * sH3[0] + b * sH3[1] + c * sH3[2], v1 = a * sH3[3] + b * sH3[4] + c * sH3[5], v2 = a * sH3[6] + b * sH3[7] + c * sH3[8];
-            if (tid < 3) { v0 += sQ[tid * 3]; v1 += sQ[tid * 3 + 1]; v2 += sQ[tid * 3 + 2]; }
-            row[0] = v0; row[1] = v1; row[2] = v2;
-        }
-        WIN_STAMP(1);
-        // ---- 2. records of the m corrections (aruco_slam.cpp:119-143), linearised at the frozen mean ----
-        if (tid < m) {
-            const int a = tid;
-            const double mu0x = sPose[0], mu0y = sPose[1], mu0t = sPose[2], sintheta = sPose[3], costheta = sPose[4];
-            const double mx = sMu[3 + 3 * a], my = sMu[4 + 3 * a], mth = sMu[5 + 3 * a];
-            double gdx = mx - mu0x, gdy = my - mu0y, gdth = mth - mu0t;
-            wrap1(gdth);
-            const double zh0 = gdx * costheta + gdy * sintheta, zh1 = -gdx * sintheta + gdy * costheta;
-            double z2 = myObs.th - gdth;
-            wrap1(z2);
-            sZe[3 * a] = myObs.x - zh0; sZe[3 * a + 1] = myObs.y - zh1; sZe[3 * a + 2] = z2;
-            sNu[3 * a] = sZe[3 * a]; sNu[3 * a + 1] = sZe[3 * a + 1]; sNu[3 * a + 2] = sZe[3 * a + 2];
-            const double G[18] = {-costheta, -sintheta, -gdx * sintheta + gdy * costheta, costheta, sintheta, 0,
-                                  sintheta, -costheta, -gdx * costheta - gdy * sintheta, -sintheta, costheta, 0,
-                                  0, 0, -1, 0, 0, 1};
-            for (int r = 0; r < 3; r++)
-                for (int c = 0; c < 3; c++) { sHr[a][r * 3 + c] = G[r * 6 + c]; sHl[a][r * 3 + c] = G[r * 6 + 3 + c]; }
-            sRd[a][0] = myObs.r[0]; sRd[a][1] = myObs.r[1]; sRd[a][2] = myObs.r[2];
-            for (int q = 0; q < 18; q++) log[WLOG_HREC + a * 18 + q] = G[q];
-            if (k == wd.K - 1) {                                    // what the frame leaves behind for whatever follows the window
-                PopRec pr;
-                pr.id = myObs.id; pr.index = (wd.li[a] - 3) / 3; pr.action = 1; pr.pad = 0;
-                pr.z[0] = myObs.x; pr.z[1] = myObs.y; pr.z[2] = myObs.th;
-                pr.r[0] = myObs.r[0]; pr.r[1] = myObs.r[1]; pr.r[2] = myObs.r[2];
-                E.d_pop[a] = pr;
-                LastObs lo;
-                lo.id = myObs.id; lo.pad = 0; lo.z[0] = myObs.x; lo.z[1] = myObs.y; lo.z[2] = myObs.th;   // update branch (aruco_slam.cpp:202)
-                E.d_last[a] = lo;
-            }
-        }
-        if (tid == 0 && slot < E.max_slots) {
-            int* st = E.d_slot_stat + 4 * slot;
-            st[0] = (int)min(n_markers[slot], (unsigned)kMarkerMax); st[1] = 0; st[2] = m; st[3] = 0;
-        }
-        ASLAM_LDS_BARRIER();
-        // the next frame's inputs are fetched while this one is solved
-        if (k + 1 < wd.K) {
-            if (tid < m) myObs = obs[(size_t)(slot + 1) * kMarkerMax + obs_idx[(size_t)(k + 1) * kWinM + tid]];
-            if (tid == 0) { const double* e = enc + (size_t)3 * (slot + 1); e_wl = e[0]; e_wr = e[1]; e_dt = e[2]; }
-        }
-        WIN_STAMP(2);
-        // ---- 3. W = P' H^T (s x 3m); 3x3 block (i, a): block row i of S, correction a ----
-        if (tid < (m + 1) * m) {
-            const int i = tid / m, a = tid - i * m;
-            double Pa[9], Pb[9];
+    if (wave < NWK) {
+        // =================================== worker waves: P in the accumulators ===================================
+        v4d acc[RW][T];
+        const double* Pimg = E.d_win_small + wsm_P(E.win_sp_max);
 #pragma unroll
-            for (int r = 0; r < 3; r++)
+        for (int rr = 0; rr < RW; rr++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    Pa[r * 3 + c] = sP[(3 * i + r) * WS + c];                    // P[i, 0]
-                    Pb[r * 3 + c] = sP[(3 * i + r) * WS + 3 + 3 * a + c];        // P[i, 1 + a]
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    const int r = 16 * (wave * RW + rr) + lk + 4 * reg, c = 16 * t + li;
+                    double v = 0.0;
+                    if (wd.piece) v = Pimg[(size_t)r * SP + c];                    // the run goes on: P as the previous piece left it
+                    else if (r < s && c < s) v = E.d_sigma[(size_t)sS[c] * ld + sS[r]];
+                    acc[rr][t][reg] = v;
                 }
-            const double* Hr = sHr[a];
-            const double* Hl = sHl[a];
+        // rows of step 0 (pose rows only: a predict) and of step 1, as they stand before any step
+        if (wave == 0) {
 #pragma unroll
-            for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++)
+                if (lk == q) {
 #pragma unroll
-                for (int c = 0; c < 3; c++)
-                    sW[(3 * i + r) * WS + 3 * a + c] = (Pa[r * 3] * Hr[c * 3] + Pa[r * 3 + 1] * Hr[c * 3 + 1] + Pa[r * 3 + 2] * Hr[c * 3 + 2]) +
-                                                       (Pb[r * 3] * Hl[c * 3] + Pb[r * 3 + 1] * Hl[c * 3 + 1] + Pb[r * 3 + 2] * Hl[c * 3 + 2]);
-        }
-        ASLAM_LDS_BARRIER();
-        WIN_STAMP(3);
-        // ---- 4. innovation matrix A = H W + R (aruco_slam.cpp:146): thread (bi, bj) forms its 3x3 block into the G image ----
-        if (act) {
-            double W0[9], W1[9];
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) { W0[r * 3 + c] = sW[r * WS + 3 * bj + c]; W1[r * 3 + c] = sW[(3 + 3 * bi + r) * WS + 3 * bj + c]; }
-            const double* Hr = sHr[bi];
-            const double* Hl = sHl[bi];
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    double v = (Hr[r * 3] * W0[c] + Hr[r * 3 + 1] * W0[3 + c] + Hr[r * 3 + 2] * W0[6 + c]) +
-                               (Hl[r * 3] * W1[c] + Hl[r * 3 + 1] * W1[3 + c] + Hl[r * 3 + 2] * W1[6 + c]);
-                    if (bi == bj && r == c) v += sRd[bi][r];
-                    sG[gpix(3 * bi + r, 3 * bj + c)] = v;
+                    for (int t = 0; t < T; t++) { sPub[0][q][16 * t + li] = acc[0][t][0]; sPub[1][q][16 * t + li] = acc[0][t][0]; }
                 }
         }
+        if (NS > 1 && sPos[1] != 255) win_publish<T, RW>(acc, 3 + 3 * sPos[1], wave, lk, li, &sPub[1][3][0], SPP);
         ASLAM_LDS_BARRIER();
-        WIN_STAMP(4);
-        // ---- block Gauss-Jordan on the f64 matrix cores.  Waves 0..3 ("workers") each keep one tile row (16 rows x 64 columns)
-        // of the 64 x 64 image (A, zero padded) in their accumulators for the whole sweep.  Step j with pivot rows / columns
-        // p = 3 j .. 3 j + 2, S = A[p,p] (the reference's S_j = H_j Sigma_{j-1} H_j^T + R_j), C = A[:,p], R = A[p,:] is ONE
-        // rank-3 product
-        //     A <- A - C~ Y~ ,   C~ = C with rows p replaced by S - I ,   Y~ = S^-1 R with columns p replaced by I + S^-1 ,
-        // which leaves S^-1 in the pivot block, S^-1 R in the pivot rows, -C S^-1 in the pivot columns (= -(H_r K_j), whose
-        // product with ze_j the pseudo-innovation nu_r collects, quirk Q1) and the Schur update everywhere else.
-        // A step is a chain of dependent LDS round trips and cross-lane moves, not arithmetic (measured), so
-        //  * only the three pivot ROWS ever leave the accumulators: the partially inverted image stays symmetric up to the sign
-        //    of the pivoted/unpivoted cross blocks (A is symmetric to rounding), so C[r][k] = +-R[k][r] and the column operand
-        //    is read from the same three rows;
-        //  * wave 4 prepares pivot j + 1 WHILE the workers apply step j: the workers publish the rows of pivot j + 2 as they
-        //    stand after step j; one phase later wave 4 applies step j + 1's rank-3 correction to those three rows itself, from
-        //    the rows and Y~ of pivot j + 1 it still holds in registers (lane = column; uniform values by v_readlane, no LDS),
-        //    inverts S and hands Y~ and the corrected rows to the workers.  One barrier per step.
-        const int tr = wave >> 1, tc0 = 2 * (wave & 1);           // tile ownership of the two products below (all eight waves)
-        const int kd = (n3 + 3) & ~3;                               // their depth: 3m, whole MFMA steps (rows / columns >= 3m of G, J are zero)
-        const int gw = wave & 3;                                    // tile row of the working waves
-        const int grow = 16 * gw + li;                              // this lane's operand row
-        double nu = (wave == 4 && lane < n3) ? sZe[lane] : 0.0;     // wave 4: innovation / pseudo-innovation of row `lane`
-        const double ze = nu;
-        double Rp0 = 0.0, Rp1 = 0.0, Rp2 = 0.0, Yp0 = 0.0, Yp1 = 0.0, Yp2 = 0.0;      // wave 4: rows and Y~ of the pivot prepared last
-        v4d ga[4];
-        if (wave < 4) {
+        for (int j = -1; j < NS; j++) {
+            if (j >= 0) {
+                const int cb = j & 1;
+                double b[T];
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const double2 lo = *reinterpret_cast<const double2*>(&sG[(16 * t + li) * WS + 16 * gw + 4 * lk]);
-                const double2 hi = *reinterpret_cast<const double2*>(&sG[(16 * t + li) * WS + 16 * gw + 4 * lk + 2]);
-                ga[t][0] = lo.x; ga[t][1] = lo.y; ga[t][2] = hi.x; ga[t][3] = hi.y;
-            }
-            gj_publish_rows(ga, 0, gw, lk, li, &sPub[0][0][0]);
-            if (m > 1) gj_publish_rows(ga, 3, gw, lk, li, &sPub[1][0][0]);
-        }
-        ASLAM_LDS_BARRIER();
-        for (int j = -1; j < m; j++) {
-            // phase j: the workers apply step j and publish the rows of pivot j + 2; wave 4 prepares pivot j + 1
-            GJ_STAMP(0);
-            if (wave == 4) {
-                if (j + 1 < m) {
-                    const int jb = (j + 1) & 1, p = 3 * (j + 1);
-                    double R0 = sPub[jb][0][lane], R1 = sPub[jb][1][lane], R2 = sPub[jb][2][lane];     // rows of pivot j + 1 as of step j - 1
-                    if (j >= 0) {
-                        // step j's correction of these rows: C~_j[p + q][k] = R_j[k][p + q] (rows behind pivot j), Y~_j from the registers
+                for (int t = 0; t < T; t++) b[t] = sB[cb][lk][16 * t + li];
 #pragma unroll
-                        for (int q = 0; q < 3; q++) {
-                            const double c0 = ASLAM_WAVE_BCAST(Rp0, p + q), c1 = ASLAM_WAVE_BCAST(Rp1, p + q), c2 = ASLAM_WAVE_BCAST(Rp2, p + q);
-                            double& R = q == 0 ? R0 : q == 1 ? R1 : R2;
-                            R = fma(-c2, Yp2, fma(-c1, Yp1, fma(-c0, Yp0, R)));
-                        }
+                for (int rr = 0; rr < RW; rr++) {
+                    const double a = sA[cb][lk][16 * (wave * RW + rr) + li];
+#pragma unroll
+                    for (int t = 0; t < T; t++) acc[rr][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[rr][t], 0, 0, 0);
+                }
+                if (j + 2 < NS) {                                   // rows of step j + 2 as they stand after step j
+                    if (wave == 0) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++)
+                            if (lk == q) {
+#pragma unroll
+                                for (int t = 0; t < T; t++) sPub[cb][q][16 * t + li] = acc[0][t][0];
+                            }
                     }
-                    double Sm[9], Si[9];
-#pragma unroll
-                    for (int c = 0; c < 3; c++) { Sm[c] = ASLAM_WAVE_BCAST(R0, p + c); Sm[3 + c] = ASLAM_WAVE_BCAST(R1, p + c); Sm[6 + c] = ASLAM_WAVE_BCAST(R2, p + c); }
-                    inv3_fast(Sm, Si);
-                    const double r0 = R0 + (lane == p ? 1.0 : 0.0), r1 = R1 + (lane == p + 1 ? 1.0 : 0.0), r2 = R2 + (lane == p + 2 ? 1.0 : 0.0);   // R~
-                    Yp0 = fma(Si[2], r2, fma(Si[1], r1, Si[0] * r0));
-                    Yp1 = fma(Si[5], r2, fma(Si[4], r1, Si[3] * r0));
-                    Yp2 = fma(Si[8], r2, fma(Si[7], r1, Si[6] * r0));
-                    sGY[jb][0][lane] = Yp0; sGY[jb][1][lane] = Yp1; sGY[jb][2][lane] = Yp2;
-                    sRow[jb][0][lane] = R0; sRow[jb][1][lane] = R1; sRow[jb][2][lane] = R2;
-                    Rp0 = R0; Rp1 = R1; Rp2 = R2;
-                    // nu_r += (C_r S^-1) ze_p for the rows behind the pivot: C[r][k] = R[k][r] there, u = S^-1 ze_p
-                    const double z0 = ASLAM_WAVE_BCAST(ze, p), z1 = ASLAM_WAVE_BCAST(ze, p + 1), z2 = ASLAM_WAVE_BCAST(ze, p + 2);
-                    const double u0 = fma(Si[2], z2, fma(Si[1], z1, Si[0] * z0)), u1 = fma(Si[5], z2, fma(Si[4], z1, Si[3] * z0)), u2 = fma(Si[8], z2, fma(Si[7], z1, Si[6] * z0));
-                    if (lane >= p + 3 && lane < n3) nu += R0 * u0 + R1 * u1 + R2 * u2;
+                    const int pn = sPos[j + 2];
+                    if (pn != 255) win_publish<T, RW>(acc, 3 + 3 * pn, wave, lk, li, &sPub[cb][3][0], SPP);
                 }
-            } else if (wave < 4 && j >= 0) {
-                // ---- apply step j: A <- A - C~ Y~ on this wave's tile row.  A operand C~[row][k = lk] from the pivot rows: rows
-                // already pivoted carry the opposite sign, the pivot rows themselves S - I; depth 3 is the zero row ----
-                const int cb = j & 1, p0 = 3 * j;
-                const double rr = sRow[cb][lk][grow];
-                double af = grow < p0 ? rr : -rr;                   // = -C~
-                if (lk < 3 && grow == p0 + lk) af += 1.0;
-#pragma unroll
-                for (int t = 0; t < 4; t++) ga[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, sGY[cb][lk][16 * t + li], ga[t], 0, 0, 0);
-                if (j + 2 < m) gj_publish_rows(ga, p0 + 6, gw, lk, li, &sPub[cb][0][0]);
             }
-            GJ_STAMP(1);
             ASLAM_LDS_BARRIER();
-            GJ_STAMP(2);
         }
-        WIN_STAMP(5);
-        // G = A^-1 into its image (gpix layout: a lane's four rows of a tile are neighbours); nu beside V (it rides the
-        // product J = G V as column 63: g = G nu)
-        if (wave < 4) {
+        // P_K for the next piece / the flush
+        double* Pout = E.d_win_small + wsm_P(E.win_sp_max);
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                double2 lo, hi;
-                lo.x = ga[t][0]; lo.y = ga[t][1]; hi.x = ga[t][2]; hi.y = ga[t][3];
-                *reinterpret_cast<double2*>(&sG[(16 * t + li) * WS + 16 * gw + 4 * lk]) = lo;
-                *reinterpret_cast<double2*>(&sG[(16 * t + li) * WS + 16 * gw + 4 * lk + 2]) = hi;
-            }
-        } else if (wave == 4) sNu[lane] = nu;
-        ASLAM_LDS_BARRIER();
-        // ---- 5. J = G V on the f64 matrix cores, same tile ownership.  V = H P' is W^T (P' is symmetric to rounding, like A above),
-        //         so the B operand is read from W's image transposed; column 63 (padding, s <= 63) is nu, so column 63 of J is g ----
-        {
-            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            const bool gcol = 16 * tc0 + 16 + li == 63;
-            for (int p0 = 0; p0 < kd; p0 += 4) {
-                const double a = sG[gpix(16 * tr + li, p0 + lk)];
-                const double b0 = sW[(16 * tc0 + li) * WS + p0 + lk], b1 = gcol ? sNu[p0 + lk] : sW[(16 * tc0 + 16 + li) * WS + p0 + lk];
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
-            }
+        for (int rr = 0; rr < RW; rr++)
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                sV[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li] = acc0[reg];
-                sV[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + 16 + li] = acc1[reg];
-            }
-        }
-        ASLAM_LDS_BARRIER();
-        if (tid < 64) log[WLOG_g + tid] = sV[tid * WS + 63];
-        WIN_STAMP(8);
-        // ---- 7. P <- P' - W J (aruco_slam.cpp:204 regrouped), mu_S += W g (:203) ----
-        {
-            v4d acc0, acc1;
+            for (int t = 0; t < T; t++)
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                acc0[reg] = sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li];
-                acc1[reg] = sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + 16 + li];
-            }
-            for (int p0 = 0; p0 < kd; p0 += 4) {
-                const double a = -sW[(16 * tr + li) * WS + p0 + lk];
-                const double b0 = sV[(p0 + lk) * WS + 16 * tc0 + li], b1 = sV[(p0 + lk) * WS + 16 * tc0 + 16 + li];
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + li] = acc0[reg];
-                sP[(16 * tr + lk + 4 * reg) * WS + 16 * tc0 + 16 + li] = acc1[reg];
-            }
-        }
-        ASLAM_LDS_BARRIER();
-        if (tid < 64) {                                             // column 63 of the product is -(W g): mu_S += W g (aruco_slam.cpp:203)
-            sMu[tid] -= sP[tid * WS + 63];
-            sP[tid * WS + 63] = 0.0;
-        }
-        WIN_STAMP(9);
-        // log G and W (both stay untouched until the next frame's steps 3 / 4, behind a barrier)
-        for (int e = tid; e < WIMG / 2; e += WCT) reinterpret_cast<double2*>(log + WLOG_W)[e] = reinterpret_cast<const double2*>(sW)[e];
-        for (int e = tid; e < 64 * 64; e += WCT) log[WLOG_G + (e >> 6) * WS + (e & 63)] = sG[gpix(e >> 6, e & 63)];      // G leaves in row-major order
-        ASLAM_LDS_BARRIER();
-        // (J's rows >= 3m and columns >= s are exact zeros - G's are - so the image V is rebuilt into next frame needs no clearing)
-        WIN_STAMP(10);
+                for (int reg = 0; reg < 4; reg++) Pout[(size_t)(16 * (wave * RW + rr) + lk + 4 * reg) * SP + 16 * t + li] = acc[rr][t][reg];
+        return;
     }
-#ifdef ASLAM_WIN_STAMPS
-#ifdef ASLAM_GJ_STAMPS
-    if ((tid & 63) == 0 && wd.K > 3) {
-        printf("tid %d gj step: work %lld barrier %lld\n", tid, gst[1] - gst[0], gst[2] - gst[1]);
+
+    // ======================================= prepare wave: lane = column (NC chunks of 64) =======================================
+    double mu[NC], pA[4][NC], pB[4][NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int col = lane + 64 * c;
+        mu[c] = col < s ? E.d_mu[sS[col]] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { pA[k][c] = 0.0; pB[k][c] = 0.0; }
     }
-#endif
-    if (tid == 0 && wd.K > 3) {
-        if (false) printf("gj step: loads+S %lld inv %lld frags+mfma %lld writeback %lld copy %lld barrier %lld | step %lld\n", gst[1] - gst[0], gst[2] - gst[1], gst[3] - gst[2],
-               gst[4] - gst[3], gst[5] - gst[4], gst[6] - gst[5], gst[6] - gst[0]);
-        printf("chain m=%d cycles: predict %lld records %lld barrier+prefetch %lld WV %lld A %lld GJ %lld G,nu+J %lld P,mu %lld logGW %lld | frame %lld\n", m,
-               stamps[1] - stamps[0], stamps[2] - stamps[1], 0LL, stamps[3] - stamps[2], stamps[4] - stamps[3], stamps[5] - stamps[4],
-               stamps[8] - stamps[5], stamps[9] - stamps[8], stamps[10] - stamps[9], stamps[10] - stamps[0]);
+    // per-frame records, lane a = correction a of the frame (aruco_slam.cpp:119-143 at the frozen mean)
+    double rze0 = 0, rze1 = 0, rze2 = 0, rR0 = 0, rR1 = 0, rR2 = 0, rg02 = 0, rg12 = 0;
+    double cth = 1.0, sth = 0.0;
+    // the first frame's inputs
+    ObsRaw nObs{};
+    {
+        const WinFrame& fr = frames[wd.first_slot];
+        if (lane < fr.m) nObs = obs[(size_t)wd.first_slot * kMarkerMax + fr.cdet[lane]];
     }
-#endif
-    // ---- the window's result on S: P_K for the flush, mu_S in place; bookkeeping of the last frame ----
-    double* small = E.d_win_small;
-    for (int e = tid; e < WIMG; e += WCT) small[WSM_P + e] = sP[e];
-    if (tid < s) E.d_mu[sS[tid]] = sMu[tid];
-    if (tid == 0) { *E.d_nlast = m; *E.d_npop = m; *E.d_m = m; }
+    double e_wl, e_wr, e_dt;
+    { const double* e = enc + (size_t)3 * wd.first_slot; e_wl = e[0]; e_wr = e[1]; e_dt = e[2]; }
+    ASLAM_LDS_BARRIER();                                           // (pairs with the workers' barrier after their first publish)
+    for (int j = -1; j < NS; j++) {
+        const int n = j + 1;                                       // the step prepared in this phase
+        if (n < NS) {
+            const int nb = n & 1;
+            const int pos = sPos[n];
+            const bool is_predict = pos == 255;
+            const int k = sFrm[n];
+            const int slot = wd.first_slot + k;
+            const int lrow = is_predict ? 0 : 3 + 3 * pos;         // first landmark row
+            double r[6][NC];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) r[i][c] = sPub[nb][i][lane + 64 * c];
+            if (j >= 0) {
+                // step j's correction of these rows: P[R][col] += sum_k Aop_j[k][R] Bop_j[k][col], from the registers
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const int R = i < 3 ? i : lrow + (i - 3);       // (a predict step has no landmark rows: rows 3..5 are then unused copies of the pose rows)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const double f = bcast_at<NC>(pA[kk], R);
+#pragma unroll
+                        for (int c = 0; c < NC; c++) r[i][c] = fma(f, pB[kk][c], r[i][c]);
+                    }
+                }
+            }
+            double* log = E.d_win_log + (size_t)(wd.log0 + n) * win_log_stride(T);
+            double A[4][NC], B[4][NC];
+            if (is_predict) {
+                // ---- predict (aruco_slam.cpp:35-73) with the final mean of the previous frame ----
+                const double delta_sl = sp.kl * (e_dt * e_wl), delta_sr = sp.kr * (e_dt * e_wr);
+                const double delta_theta = (delta_sr - delta_sl) / (2 * sp.b);
+                const double delta_s = 0.5 * (delta_sr + delta_sl);
+                const double m0 = ASLAM_WAVE_BCAST(mu[0], 0), m1 = ASLAM_WAVE_BCAST(mu[0], 1), m2 = ASLAM_WAVE_BCAST(mu[0], 2);
+                double th = m2 + delta_theta;
+                wrap1(th);
+                // the two sincos of the frame in one call: even lanes the mid-step heading, odd lanes the new heading
+                double sv, cv;
+                sincos((lane & 1) ? th : m2 + 0.5 * delta_theta, &sv, &cv);
+                const double cm = ASLAM_WAVE_BCAST(cv, 0), sm = ASLAM_WAVE_BCAST(sv, 0);
+                cth = ASLAM_WAVE_BCAST(cv, 1); sth = ASLAM_WAVE_BCAST(sv, 1);
+                const double ua = -delta_s * sm, ub = delta_s * cm;                 // H3 = I + [ua ub 0]^T e2^T
+                const double f = 0.5 * sp.kl * e_dt;                                 // kl for BOTH wheels (quirk Q7)
+                const double su0 = sp.Q_k * fabs(e_wl), su1 = sp.Q_k * fabs(e_wr);
+                const double P22 = ASLAM_WAVE_BCAST(r[2][0], 2);
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const int col = lane + 64 * c;
+                    const double u = col == 0 ? ua : col == 1 ? ub : 0.0;
+                    const double w0 = col == 0 ? f * cm : col == 1 ? f * sm : col == 2 ? f * (1 / sp.b) : 0.0;      // wkh column 0
+                    const double w1 = col == 0 ? f * cm : col == 1 ? f * sm : col == 2 ? f * (-1 / sp.b) : 0.0;     // wkh column 1
+                    A[0][c] = u;                       B[0][c] = r[2][c];
+                    A[1][c] = fma(P22, u, r[2][c]);    B[1][c] = u;
+                    A[2][c] = su0 * w0;                B[2][c] = w0;
+                    A[3][c] = su1 * w1;                B[3][c] = w1;
+                }
+                if (lane == 0) mu[0] = m0 + delta_s * cm;
+                if (lane == 1) mu[0] = m1 + delta_s * sm;
+                if (lane == 2) mu[0] = th;
+                // ---- the frame's records at the frozen mean (pose just predicted, landmarks as the previous frame left them) ----
+                const WinFrame& fr = frames[slot];
+#pragma unroll
+                for (int c = 0; c < NC; c++) sMu[lane + 64 * c] = mu[c];
+                __builtin_amdgcn_wave_barrier();
+                if (lane < fr.m) {
+                    const int q = 3 + 3 * fr.cpos[lane];
+                    const double mu0x = sMu[0], mu0y = sMu[1], mu0t = sMu[2];
+                    const double mx = sMu[q], my = sMu[q + 1], mth = sMu[q + 2];
+                    const double gdx = mx - mu0x, gdy = my - mu0y;
+                    double gdth = mth - mu0t;
+                    wrap1(gdth);
+                    const double zh0 = gdx * cth + gdy * sth, zh1 = -gdx * sth + gdy * cth;
+                    double z2 = nObs.th - gdth;
+                    wrap1(z2);
+                    rze0 = nObs.x - zh0; rze1 = nObs.y - zh1; rze2 = z2;
+                    rg02 = -gdx * sth + gdy * cth; rg12 = -gdx * cth - gdy * sth;
+                    rR0 = nObs.r[0]; rR1 = nObs.r[1]; rR2 = nObs.r[2];
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0 && slot < E.max_slots) {
+                    int* st = E.d_slot_stat + 4 * slot;
+                    st[0] = fr.n_markers; st[1] = 0; st[2] = fr.m; st[3] = fr.npop - fr.m;
+                }
+                if (wd.last && k == wd.K - 1) {
+                    // what the window's last frame leaves behind for whatever follows: pop list, last_observed_marker_ (aruco_slam.cpp:202, 263)
+                    if (lane < fr.npop) {
+                        const ObsRaw o = obs[(size_t)slot * kMarkerMax + fr.pdet[lane]];
+                        const bool upd = fr.pact[lane] == 1;
+                        PopRec pr;
+                        pr.id = o.id; pr.index = fr.pidx[lane]; pr.action = upd ? 1 : 2; pr.pad = 0;
+                        pr.z[0] = o.x; pr.z[1] = o.y; pr.z[2] = o.th;
+                        pr.r[0] = o.r[0]; pr.r[1] = o.r[1]; pr.r[2] = o.r[2];
+                        E.d_pop[lane] = pr;
+                        LastObs lo;
+                        lo.id = o.id; lo.pad = 0;
+                        const double nanv = __builtin_nan("");
+                        lo.z[0] = upd ? o.x : nanv; lo.z[1] = upd ? o.y : nanv; lo.z[2] = upd ? o.th : nanv;   // stationary: last_observation_ stays unset
+                        E.d_last[lane] = lo;
+                    }
+                    if (lane == 0) { *E.d_nlast = fr.npop; *E.d_npop = fr.npop; *E.d_m = fr.m; }
+                }
+                // the next frame's inputs are fetched while this one is solved
+                if (k + 1 < wd.K) {
+                    const WinFrame& fn = frames[slot + 1];
+                    if (lane < fn.m) nObs = obs[(size_t)(slot + 1) * kMarkerMax + fn.cdet[lane]];
+                    const double* e = enc + (size_t)3 * (slot + 1);
+                    e_wl = e[0]; e_wr = e[1]; e_dt = e[2];
+                }
+                if (lane < kWinHdr) {
+                    double hv = 0.0;
+                    if (lane == WH_POS) hv = -1.0;
+                    if (lane == WH_A) hv = ua;
+                    if (lane == WH_B) hv = ub;
+                    log[3 * SP + lane] = hv;
+                }
+            } else {
+                // ---- correction a of frame k: c = H P, S = c H^T + R, Kt = S^-1 c ----
+                const int a = sIdx[n];
+                const double ze0 = ASLAM_WAVE_BCAST(rze0, a), ze1 = ASLAM_WAVE_BCAST(rze1, a), ze2 = ASLAM_WAVE_BCAST(rze2, a);
+                const double R0 = ASLAM_WAVE_BCAST(rR0, a), R1 = ASLAM_WAVE_BCAST(rR1, a), R2 = ASLAM_WAVE_BCAST(rR2, a);
+                const double g02 = ASLAM_WAVE_BCAST(rg02, a), g12 = ASLAM_WAVE_BCAST(rg12, a);
+                // Gxm = [ -c -s g02  c  s 0 ;  s -c g12 -s  c 0 ;  0 0 -1  0 0 1 ]   (aruco_slam.cpp:140-143)
+                double cc[3][NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    cc[0][c] = (-cth * r[0][c] - sth * r[1][c] + g02 * r[2][c]) + (cth * r[3][c] + sth * r[4][c]);
+                    cc[1][c] = (sth * r[0][c] - cth * r[1][c] + g12 * r[2][c]) + (-sth * r[3][c] + cth * r[4][c]);
+                    cc[2][c] = r[5][c] - r[2][c];
+                }
+                double Sm[9], Si[9];
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++) {
+                    const double p0 = ASLAM_WAVE_BCAST(cc[kk][0], 0), p1 = ASLAM_WAVE_BCAST(cc[kk][0], 1), p2 = ASLAM_WAVE_BCAST(cc[kk][0], 2);
+                    const double l0 = bcast_at<NC>(cc[kk], lrow), l1 = bcast_at<NC>(cc[kk], lrow + 1), l2 = bcast_at<NC>(cc[kk], lrow + 2);
+                    Sm[kk * 3 + 0] = (-cth * p0 - sth * p1 + g02 * p2) + (cth * l0 + sth * l1);
+                    Sm[kk * 3 + 1] = (sth * p0 - cth * p1 + g12 * p2) + (-sth * l0 + cth * l1);
+                    Sm[kk * 3 + 2] = l2 - p2;
+                }
+                Sm[0] += R0; Sm[4] += R1; Sm[8] += R2;
+                inv3_fast(Sm, Si);
+                const double w0 = Si[0] * ze0 + Si[1] * ze1 + Si[2] * ze2, w1 = Si[3] * ze0 + Si[4] * ze1 + Si[5] * ze2,
+                             w2 = Si[6] * ze0 + Si[7] * ze1 + Si[8] * ze2;
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    // K = (P H^T) S^-1, (P H^T) = c^T:  Kt[k][col] = sum_k' c[k'][col] Si[k'][k]
+                    const double k0 = cc[0][c] * Si[0] + cc[1][c] * Si[3] + cc[2][c] * Si[6];
+                    const double k1 = cc[0][c] * Si[1] + cc[1][c] * Si[4] + cc[2][c] * Si[7];
+                    const double k2 = cc[0][c] * Si[2] + cc[1][c] * Si[5] + cc[2][c] * Si[8];
+                    mu[c] += k0 * ze0 + k1 * ze1 + k2 * ze2;                       // mu_ += K ze (aruco_slam.cpp:203)
+                    A[0][c] = -k0; A[1][c] = -k1; A[2][c] = -k2; A[3][c] = 0.0;
+                    B[0][c] = cc[0][c]; B[1][c] = cc[1][c]; B[2][c] = cc[2][c]; B[3][c] = 0.0;
+                }
+                (void)w0; (void)w1; (void)w2;
+                if (lane < kWinHdr) {
+                    double hv = 0.0;
+                    if (lane == WH_TYPE) hv = 1.0;
+                    if (lane == WH_POS) hv = (double)pos;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) if (lane == WH_SI + q) hv = Si[q];      // (static register numbers: no scratch array)
+                    if (lane == WH_ZE) hv = ze0;
+                    if (lane == WH_ZE + 1) hv = ze1;
+                    if (lane == WH_ZE + 2) hv = ze2;
+                    if (lane == WH_C) hv = cth;
+                    if (lane == WH_S) hv = sth;
+                    if (lane == WH_G02) hv = g02;
+                    if (lane == WH_G12) hv = g12;
+                    log[3 * SP + lane] = hv;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    sA[nb][kk][lane + 64 * c] = A[kk][c];
+                    sB[nb][kk][lane + 64 * c] = B[kk][c];
+                    pA[kk][c] = A[kk][c]; pB[kk][c] = B[kk][c];
+                    if (kk < 3) log[kk * SP + lane + 64 * c] = A[kk][c];
+                }
+        }
+        ASLAM_LDS_BARRIER();
+    }
+    // ---- mu_S in place ----
+#pragma unroll
+    for (int c = 0; c < NC; c++) { const int col = lane + 64 * c; if (col < s) E.d_mu[sS[col]] = mu[c]; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Replay of the log: workgroup (x = j, y = i) carries Lambda[:, 16j .. 16j+15], Gamma[16i .. 16i+15, :], Psi block (i, j).
-// The next frame's record (G, W images: 68 KB) is fetched into registers while the current one is multiplied.
-constexpr int WPF = (WLOG_STRIDE / 2 + 255) / 256;   // 16-byte loads per thread and frame (26): the whole record, unconditionally
-constexpr int WREC = WPF * 256 * 2;                  // doubles staged per frame (a little past the record: the log has slack)
+// Replay of a piece's log on Lambda: workgroup b carries columns 16 b .. 16 b + 15 (all SP rows) and its entries of psi.
+// Per step: t = H Lambda (3 x 16), u = S^-1 t, Lambda += Aop^T t, psi += t^T (S^-1 ze); t and u are logged for the Psi product.
+template <int T>
+__global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd, int nsteps) {
+    constexpr int SP = 16 * T, EPT = SP * WBW / 256;              // Lambda entries per thread
+    __shared__ double sLam[SP][WBW + 1];
+    __shared__ double sRec[2][3 * SP + kWinHdr];
+    __shared__ double sT[4][WBW], sU[4][WBW];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int ls = win_log_stride(T), ts = win_tlog_stride(T);
+    double* Lam = E.d_win_small + wsm_LAM(E.win_sp_max);
+    double* psi = E.d_win_small + wsm_psi(E.win_sp_max);
+    for (int e = tid; e < SP * WBW; e += 256) {
+        const int r = e / WBW, c = e % WBW;
+        sLam[r][c] = wd.piece ? Lam[(size_t)r * SP + WBW * b + c] : (r == WBW * b + c ? 1.0 : 0.0);
+    }
+    double ps = (tid < WBW && wd.piece) ? psi[WBW * b + tid] : 0.0;
+    const double* logp = E.d_win_log + (size_t)wd.log0 * ls;
+    double* tlog = E.d_win_tlog + (size_t)wd.log0 * ts;
+    constexpr int RPT = (3 * SP + kWinHdr + 255) / 256;           // record doubles per thread
+    double pf[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; q++) { const int e = tid + 256 * q; pf[q] = (e < 3 * SP + kWinHdr && nsteps > 0) ? logp[e] : 0.0; }
+    if (tid < 4 * WBW) { (&sT[0][0])[tid] = 0.0; (&sU[0][0])[tid] = 0.0; }
+    __syncthreads();
+    for (int n = 0; n < nsteps; n++) {
+        double* rec = sRec[n & 1];
+#pragma unroll
+        for (int q = 0; q < RPT; q++) { const int e = tid + 256 * q; if (e < 3 * SP + kWinHdr) rec[e] = pf[q]; }
+        if (n + 1 < nsteps) {                                       // in flight while this step is applied
+            const double* nx = logp + (size_t)(n + 1) * ls;
+#pragma unroll
+            for (int q = 0; q < RPT; q++) { const int e = tid + 256 * q; pf[q] = e < 3 * SP + kWinHdr ? nx[e] : 0.0; }
+        }
+        ASLAM_LDS_BARRIER();
+        const double* hd = rec + 3 * SP;
+        if (hd[WH_TYPE] == 0.0) {
+            // predict: Lambda <- D Lambda (rows 0, 1 += (a, b) row 2); nothing for Psi / psi
+            if (tid < WBW) { sLam[0][tid] += hd[WH_A] * sLam[2][tid]; sLam[1][tid] += hd[WH_B] * sLam[2][tid]; }
+            if (tid < 8 * WBW) {                                    // t = u = 0 for this step
+                const int row = tid / WBW, c = tid % WBW;
+                tlog[(size_t)n * ts + row * SP + WBW * b + c] = 0.0;
+            }
+            ASLAM_LDS_BARRIER();
+            continue;
+        }
+        const int lrow = 3 + 3 * (int)hd[WH_POS];
+        if (tid < WBW) {
+            const int c = tid;
+            const double cth = hd[WH_C], sth = hd[WH_S], g02 = hd[WH_G02], g12 = hd[WH_G12];
+            const double r0 = sLam[0][c], r1 = sLam[1][c], r2 = sLam[2][c], l0 = sLam[lrow][c], l1 = sLam[lrow + 1][c], l2 = sLam[lrow + 2][c];
+            const double t0 = (-cth * r0 - sth * r1 + g02 * r2) + (cth * l0 + sth * l1);
+            const double t1 = (sth * r0 - cth * r1 + g12 * r2) + (-sth * l0 + cth * l1);
+            const double t2 = l2 - r2;
+            const double* Si = hd + WH_SI;
+            // u = S^-1 t (Z <- Z - (H Y)^T S^-1 (H Y));  psi += t^T (S^-1 ze)
+            const double u0 = Si[0] * t0 + Si[1] * t1 + Si[2] * t2, u1 = Si[3] * t0 + Si[4] * t1 + Si[5] * t2, u2 = Si[6] * t0 + Si[7] * t1 + Si[8] * t2;
+            const double z0 = hd[WH_ZE], z1 = hd[WH_ZE + 1], z2 = hd[WH_ZE + 2];
+            const double w0 = Si[0] * z0 + Si[1] * z1 + Si[2] * z2, w1 = Si[3] * z0 + Si[4] * z1 + Si[5] * z2, w2 = Si[6] * z0 + Si[7] * z1 + Si[8] * z2;
+            ps += t0 * w0 + t1 * w1 + t2 * w2;
+            sT[0][c] = t0; sT[1][c] = t1; sT[2][c] = t2;
+            sU[0][c] = u0; sU[1][c] = u1; sU[2][c] = u2;
+        }
+        ASLAM_LDS_BARRIER();
+        if (tid < 8 * WBW) {
+            const int row = tid / WBW, c = tid % WBW;
+            tlog[(size_t)n * ts + row * SP + WBW * b + c] = row < 4 ? sT[row][c] : sU[row - 4][c];
+        }
+        // Lambda[r][c] += sum_k Aop[k][r] t[k][c]
+#pragma unroll
+        for (int q = 0; q < EPT; q++) {
+            const int e = tid + 256 * q, r = e / WBW, c = e % WBW;
+            sLam[r][c] += rec[r] * sT[0][c] + rec[SP + r] * sT[1][c] + rec[2 * SP + r] * sT[2][c];
+        }
+        ASLAM_LDS_BARRIER();
+    }
+    for (int e = tid; e < SP * WBW; e += 256) { const int r = e / WBW, c = e % WBW; Lam[(size_t)r * SP + WBW * b + c] = sLam[r][c]; }
+    if (tid < WBW) psi[WBW * b + tid] = ps;
+}
 
-__global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd) {
-    __shared__ __align__(16) double sRec[WREC];          // one logged frame: G | W | g | H3 | Jacobians
-    __shared__ double sLam[64][17];            // Lambda columns (s x 16)
-    __shared__ double sGam[16][WS];            // Gamma rows (16 x s)
-    __shared__ double sB[64][17], sGB[64][17]; // B = H D Lambda (3m x 16), G B
-    __shared__ double sA[16][WS], sAG[16][WS]; // A = Gamma D^T H^T (16 x 3m), A G
-    __shared__ double sPsi[16][17], spsi[16];
-    const double* sG = sRec + WLOG_G;
-    const double* sW = sRec + WLOG_W;
-    const double* sgv = sRec + WLOG_g;
-    const double* sH3 = sRec + WLOG_H3;
-    const double (*sHrec)[18] = reinterpret_cast<const double (*)[18]>(sRec + WLOG_HREC);
-    double (*sPsiPart)[16][16] = reinterpret_cast<double (*)[16][16]>(&sAG[0][0]);   // A G is dead once Gamma has been updated
+// Psi (+)= sum over the piece's steps of t^T u on the f64 matrix cores: workgroup = tile row, wave w = tile columns w, w + 4, ...
+template <int T>
+__global__ __launch_bounds__(256) void k_ekf_win_psi(EkfState E, WinDesc wd, int nsteps) {
+    constexpr int SP = 16 * T, TW = (T + 3) / 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const int bj = blockIdx.x, bi = blockIdx.y;
-    const int m = wd.m, n3 = 3 * m;
-    // wd.cont = index of this piece within its run (0 = first): piece p reads set (p - 1) & 1 and writes set p & 1
-    const double* rsmall = E.d_win_small + ((wd.cont - 1) & 1) * WSM_SET;
-    double* small = E.d_win_small + (wd.cont & 1) * WSM_SET;
-    if (wd.cont) {                                                  // the run goes on: the accumulators as the previous scan left them
-        for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; sLam[r][c] = rsmall[WSM_LAM + r * WS + 16 * bj + c]; }
-        for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; sGam[r][c] = rsmall[WSM_GAM + (16 * bi + r) * WS + c]; }
-        { const int r = tid >> 4, c = tid & 15; sPsi[r][c] = rsmall[WSM_PSI + (16 * bi + r) * WS + 16 * bj + c]; }
-        if (tid < 16) spsi[tid] = rsmall[WSM_psi + 16 * bi + tid];
-    } else {                                                        // Lambda = Gamma = I, Psi = 0, psi = 0
-        for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; sLam[r][c] = (r == 16 * bj + c && r < wd.s) ? 1.0 : 0.0; }
-        for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; sGam[r][c] = (c == 16 * bi + r && c < wd.s) ? 1.0 : 0.0; }
-        for (int e = tid; e < 16 * 16; e += 256) sPsi[e >> 4][e & 15] = 0.0;
-        if (tid < 16) spsi[tid] = 0.0;
+    const int tr = blockIdx.x;
+    const int ts = win_tlog_stride(T);
+    double* Psi = E.d_win_small + wsm_PSI(E.win_sp_max);
+    const double* tlog = E.d_win_tlog + (size_t)wd.log0 * ts;
+    v4d acc[TW];
+#pragma unroll
+    for (int q = 0; q < TW; q++) {
+        const int tc = wave + 4 * q;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++)
+            acc[q][reg] = (wd.piece && tc < T) ? Psi[(size_t)(16 * tr + lk + 4 * reg) * SP + 16 * tc + li] : 0.0;
     }
-    for (int e = tid; e < 64 * 17; e += 256) { (&sB[0][0])[e] = 0.0; (&sGB[0][0])[e] = 0.0; }
-    for (int e = tid; e < 16 * WS; e += 256) { (&sA[0][0])[e] = 0.0; (&sAG[0][0])[e] = 0.0; }
-    double pfx[WPF], pfy[WPF];
-    {
-        const double2* rec = reinterpret_cast<const double2*>(E.d_win_log + (size_t)wd.log0 * WLOG_STRIDE) + tid;
+    // A[i][k] = t[k][16 tr + i] (lane k * 16 + i), B[k][j] = u[k][16 tc + j]
+    for (int n = 0; n < nsteps; n++) {
+        const double* st = tlog + (size_t)n * ts;
+        const double a = st[lk * SP + 16 * tr + li];
 #pragma unroll
-        for (int q = 0; q < WPF; q++) { const double2 v = rec[256 * q]; pfx[q] = v.x; pfy[q] = v.y; }
+        for (int q = 0; q < TW; q++) {
+            const int tc = wave + 4 * q;
+            if (tc < T) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, st[(4 + lk) * SP + 16 * tc + li], acc[q], 0, 0, 0);
+        }
     }
-    __syncthreads();
-    for (int k = 0; k < wd.K; k++) {
 #pragma unroll
-        for (int q = 0; q < WPF; q++) { double2 v; v.x = pfx[q]; v.y = pfy[q]; reinterpret_cast<double2*>(sRec)[tid + 256 * q] = v; }
-        ASLAM_LDS_BARRIER();
-        if (k + 1 < wd.K) {                                         // in flight while this frame is multiplied
-            const double2* rec = reinterpret_cast<const double2*>(E.d_win_log + (size_t)(wd.log0 + k + 1) * WLOG_STRIDE) + tid;
+    for (int q = 0; q < TW; q++) {
+        const int tc = wave + 4 * q;
+        if (tc < T) {
 #pragma unroll
-            for (int q = 0; q < WPF; q++) { const double2 v = rec[256 * q]; pfx[q] = v.x; pfy[q] = v.y; }
+            for (int reg = 0; reg < 4; reg++) Psi[(size_t)(16 * tr + lk + 4 * reg) * SP + 16 * tc + li] = acc[q][reg];
         }
-        // D Lambda (rows 0..2) and Gamma D^T (columns 0..2)
-        if (tid < 16) {
-            const double a = sLam[0][tid], b = sLam[1][tid], c = sLam[2][tid];
-            sLam[0][tid] = sH3[0] * a + sH3[1] * b + sH3[2] * c;
-            sLam[1][tid] = sH3[3] * a + sH3[4] * b + sH3[5] * c;
-            sLam[2][tid] = sH3[6] * a + sH3[7] * b + sH3[8] * c;
-        } else if (tid < 32) {
-            const int r = tid - 16;
-            const double a = sGam[r][0], b = sGam[r][1], c = sGam[r][2];
-            sGam[r][0] = a * sH3[0] + b * sH3[1] + c * sH3[2];
-            sGam[r][1] = a * sH3[3] + b * sH3[4] + c * sH3[5];
-            sGam[r][2] = a * sH3[6] + b * sH3[7] + c * sH3[8];
-        }
-        ASLAM_LDS_BARRIER();
-        // B[3a+r][c] = Hr_a[r,:] Lambda'[0:3, c] + Hl_a[r,:] Lambda'[3+3a .. , c];   A[r'][3a+r] = Gamma'[r', 0:3] Hr_a[r,:]^T + Gamma'[r', 3+3a ..] Hl_a[r,:]^T
-        for (int e = tid; e < n3 * 16; e += 256) {
-            const int row = e >> 4, c = e & 15, a = row / 3, r = row - 3 * a;
-            const double* h = &sHrec[a][r * 6];
-            sB[row][c] = (h[0] * sLam[0][c] + h[1] * sLam[1][c] + h[2] * sLam[2][c]) +
-                         (h[3] * sLam[3 + 3 * a][c] + h[4] * sLam[4 + 3 * a][c] + h[5] * sLam[5 + 3 * a][c]);
-        }
-        for (int e = tid; e < 16 * n3; e += 256) {
-            const int rp = e / n3, col = e - rp * n3, a = col / 3, r = col - 3 * a;
-            const double* h = &sHrec[a][r * 6];
-            const double* g = sGam[rp];
-            sA[rp][col] = (g[0] * h[0] + g[1] * h[1] + g[2] * h[2]) + (g[3 + 3 * a] * h[3] + g[4 + 3 * a] * h[4] + g[5 + 3 * a] * h[5]);
-        }
-        ASLAM_LDS_BARRIER();
-        // GB = G B (wave w: tile row w), AG = A G (wave w: tile column w)
-        {
-            v4d accB = {0.0, 0.0, 0.0, 0.0}, accA = {0.0, 0.0, 0.0, 0.0};
-            for (int p0 = 0; p0 < 64; p0 += 4) {
-                const double a1 = sG[(16 * wave + li) * WS + p0 + lk], b1 = sB[p0 + lk][li];
-                accB = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accB, 0, 0, 0);
-                const double a2 = sA[li][p0 + lk], b2 = sG[(p0 + lk) * WS + 16 * wave + li];
-                accA = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accA, 0, 0, 0);
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) { sGB[16 * wave + lk + 4 * reg][li] = accB[reg]; sAG[lk + 4 * reg][16 * wave + li] = accA[reg]; }
-        }
-        ASLAM_LDS_BARRIER();
-        // Lambda -= W GB (wave w: tile row w), Gamma -= AG V = AG W^T (wave w: tile column w), Psi += A GB (depth split over the waves)
-        {
-            v4d accL, accG, accP = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) { accL[reg] = sLam[16 * wave + lk + 4 * reg][li]; accG[reg] = sGam[lk + 4 * reg][16 * wave + li]; }
-            for (int p0 = 0; p0 < 64; p0 += 4) {
-                const double a1 = -sW[(16 * wave + li) * WS + p0 + lk], b1 = sGB[p0 + lk][li];
-                accL = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accL, 0, 0, 0);
-                const double a2 = -sAG[li][p0 + lk], b2 = sW[(16 * wave + li) * WS + p0 + lk];      // V = W^T
-                accG = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accG, 0, 0, 0);
-            }
-            for (int p0 = 16 * wave; p0 < 16 * wave + 16; p0 += 4) {
-                const double a3 = sA[li][p0 + lk], b3 = sGB[p0 + lk][li];
-                accP = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, accP, 0, 0, 0);
-            }
-            double ps = 0;                                          // psi += A g
-            if (tid < 16) for (int c = 0; c < n3; c++) ps += sA[tid][c] * sgv[c];
-            ASLAM_LDS_BARRIER();                                    // every wave is done with A G (its LDS doubles as the Psi partials)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                sLam[16 * wave + lk + 4 * reg][li] = accL[reg];
-                sGam[lk + 4 * reg][16 * wave + li] = accG[reg];
-                sPsiPart[wave][lk + 4 * reg][li] = accP[reg];
-            }
-            if (tid < 16) spsi[tid] += ps;
-        }
-        ASLAM_LDS_BARRIER();
-        { const int r = tid >> 4, c = tid & 15; sPsi[r][c] += (sPsiPart[0][r][c] + sPsiPart[1][r][c]) + (sPsiPart[2][r][c] + sPsiPart[3][r][c]); }
-        ASLAM_LDS_BARRIER();
     }
-    if (bi == 0) for (int e = tid; e < 64 * 16; e += 256) { const int r = e >> 4, c = e & 15; small[WSM_LAM + r * WS + 16 * bj + c] = sLam[r][c]; }
-    if (bj == 0) for (int e = tid; e < 16 * 64; e += 256) { const int r = e >> 6, c = e & 63; small[WSM_GAM + (16 * bi + r) * WS + c] = sGam[r][c]; }
-    { const int r = tid >> 4, c = tid & 15; small[WSM_PSI + (16 * bi + r) * WS + 16 * bj + c] = sPsi[r][c]; }
-    if (bj == 0 && tid < 16) small[WSM_psi + 16 * bi + tid] = spsi[tid];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The one pass over Sigma per window.  Tile (r0, c0), 64 x 64: T = Psi Y_0tile, Sigma_tile -= X_0tile T (formed transposed so
-// that the read-modify-write of the column-major Sigma is coalesced, as k_ekf_apply does), then the rows / columns that belong to
-// S are replaced: row S_p <- (Lambda Y_0)[p, :], column S_q <- (X_0 Gamma)[:, q], (S_p, S_q) <- P_K[p][q]; mu_R += X_0 psi.
-__global__ __launch_bounds__(256) void k_ekf_win_flush(EkfState E, WinDesc wd) {
-    __shared__ __align__(16) double sM[WIMG];          // Psi, later Lambda / Gamma
-    __shared__ double sY[64][64];                      // Y_0 tile: [p][column]
-    __shared__ double sX[64][64];                      // X_0^T tile: [p][row]
-    __shared__ double sT[64][64];                      // product tile
-    __shared__ int sRowPos[64], sColPos[64], sAnyRow, sAnyCol;
+// Per 64 columns of Sigma: U = Psi Y_0blk -> d_T, Y_K = Lambda Y_0blk -> d_V (both SP x 64, matrix cores), mu_R += Y_0^T psi.
+// Y_0blk passes through LDS in chunks of 64 rows (B operand); Psi / Lambda come straight from L2 in MFMA layout (A[i][k] in lane
+// 16 k + i).  Wave w owns columns 16 w .. 16 w + 15 of the block and all T tile rows of both products.
+template <int T>
+__global__ __launch_bounds__(256) void k_ekf_win_thin(EkfState E, WinDesc wd) {
+    constexpr int SP = 16 * T, YS = 66;
+    __shared__ double sY[64 * YS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int li = lane & 15, lk = lane >> 4;
     const int ld = E.ld;
     const int N = 3 + 3 * (*E.d_L);
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    if (r0 >= N || c0 >= N) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int li = lane & 15, lk = lane >> 4;
-    const int s = wd.s;
-    const double* small = E.d_win_small;                          // P_K
-    const double* acc_set = E.d_win_small + (wd.cont & 1) * WSM_SET;   // the accumulators as the run's LAST scan piece (index wd.cont) left them
-    double sig[4][4];
+    const int c0 = blockIdx.x * 64;
+    if (c0 >= N) return;
+    const int s = 3 + 3 * wd.nS;
+    const double* Psi = E.d_win_small + wsm_PSI(E.win_sp_max);
+    const double* Lam = E.d_win_small + wsm_LAM(E.win_sp_max);
+    const double* psi = E.d_win_small + wsm_psi(E.win_sp_max);
+    v4d aU[T], aY[T];
 #pragma unroll
-    for (int ri = 0; ri < 4; ri++)
+    for (int tr = 0; tr < T; tr++) { aU[tr] = v4d{0.0, 0.0, 0.0, 0.0}; aY[tr] = v4d{0.0, 0.0, 0.0, 0.0}; }
+    double macc = 0.0;
+    for (int ch = 0; ch < SP / 64; ch++) {
+        if (ch) __syncthreads();
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int p = e >> 6, x = e & 63;
+            sY[p * YS + x] = c0 + x < N ? E.d_Wt[(size_t)(64 * ch + p) * ld + c0 + x] : 0.0;
+        }
+        __syncthreads();
+        for (int p0 = 0; p0 < 64; p0 += 4) {
+            const double bv = sY[(p0 + lk) * YS + 16 * wave + li];
+#pragma unroll
+            for (int tr = 0; tr < T; tr++) {
+                const size_t off = (size_t)(16 * tr + li) * SP + 64 * ch + p0 + lk;
+                aU[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(Psi[off], bv, aU[tr], 0, 0, 0);
+                aY[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lam[off], bv, aY[tr], 0, 0, 0);
+            }
+        }
+        if (tid < 64)
+            for (int p = 0; p < 64 && 64 * ch + p < s; p++) macc += sY[p * YS + tid] * psi[64 * ch + p];
+    }
+#pragma unroll
+    for (int tr = 0; tr < T; tr++)
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-            const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
-            sig[ri][reg] = (r < N && c < N) ? E.d_sigma[(size_t)c * ld + r] : 0.0;
+            const int p = 16 * tr + lk + 4 * reg, c = c0 + 16 * wave + li;
+            if (c < N) { E.d_T[(size_t)p * ld + c] = aU[tr][reg]; E.d_V[(size_t)p * ld + c] = aY[tr][reg]; }
         }
-    for (int e = tid; e < WIMG; e += 256) sM[e] = acc_set[WSM_PSI + e];
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int p = e >> 6, x = e & 63;
-        sY[p][x] = (p < s && c0 + x < N) ? E.d_V[(size_t)p * ld + c0 + x] : 0.0;
-        sX[p][x] = (p < s && r0 + x < N) ? E.d_Wt[(size_t)p * ld + r0 + x] : 0.0;
-    }
-    if (tid < 64) {
-        sRowPos[tid] = r0 + tid < N ? E.d_win_sidx[r0 + tid] : -1;
-        sColPos[tid] = c0 + tid < N ? E.d_win_sidx[c0 + tid] : -1;
-    }
-    if (tid == 0) { sAnyRow = 0; sAnyCol = 0; }
-    __syncthreads();
-    if (tid < 64) { if (sRowPos[tid] >= 0) sAnyRow = 1; if (sColPos[tid] >= 0) sAnyCol = 1; }
-    // T = Psi Y_0tile: wave w owns columns 16w .. 16w+15 and all four 16-row tiles
-    {
-        v4d acc[4];
-#pragma unroll
-        for (int qi = 0; qi < 4; qi++) acc[qi] = v4d{0.0, 0.0, 0.0, 0.0};
-        for (int p0 = 0; p0 < 64; p0 += 4) {
-            const double b = sY[p0 + lk][16 * wave + li];
-#pragma unroll
-            for (int qi = 0; qi < 4; qi++) acc[qi] = __builtin_amdgcn_mfma_f64_16x16x4f64(sM[(16 * qi + li) * WS + p0 + lk], b, acc[qi], 0, 0, 0);
-        }
-#pragma unroll
-        for (int qi = 0; qi < 4; qi++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) sT[16 * qi + lk + 4 * reg][16 * wave + li] = acc[qi][reg];
-    }
-    __syncthreads();
-    const bool anyRow = sAnyRow != 0, anyCol = sAnyCol != 0;       // uniform
-    // Sigma tile (transposed product): D'[c][r] = sum_p T[p][c] X_0^T[p][r]
-    {
-        v4d acc[4];
-#pragma unroll
-        for (int ri = 0; ri < 4; ri++) acc[ri] = v4d{0.0, 0.0, 0.0, 0.0};
-        for (int p0 = 0; p0 < 64; p0 += 4) {
-            const double a = sT[p0 + lk][16 * wave + li];
-#pragma unroll
-            for (int ri = 0; ri < 4; ri++) acc[ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[p0 + lk][16 * ri + li], acc[ri], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ri = 0; ri < 4; ri++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) sig[ri][reg] -= acc[ri][reg];
-    }
-    if (anyRow) {
-        // rows of S: (Lambda Y_0)[p][c]
-        __syncthreads();
-        for (int e = tid; e < WIMG; e += 256) sM[e] = acc_set[WSM_LAM + e];
-        __syncthreads();
-        v4d acc[4];
-#pragma unroll
-        for (int qi = 0; qi < 4; qi++) acc[qi] = v4d{0.0, 0.0, 0.0, 0.0};
-        for (int p0 = 0; p0 < 64; p0 += 4) {
-            const double b = sY[p0 + lk][16 * wave + li];
-#pragma unroll
-            for (int qi = 0; qi < 4; qi++) acc[qi] = __builtin_amdgcn_mfma_f64_16x16x4f64(sM[(16 * qi + li) * WS + p0 + lk], b, acc[qi], 0, 0, 0);
-        }
-#pragma unroll
-        for (int qi = 0; qi < 4; qi++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) sT[16 * qi + lk + 4 * reg][16 * wave + li] = acc[qi][reg];     // sT[p][column]
-        __syncthreads();
-#pragma unroll
-        for (int ri = 0; ri < 4; ri++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int cl = 16 * wave + lk + 4 * reg, rl = 16 * ri + li;
-                const int p = sRowPos[rl];
-                if (p >= 0) sig[ri][reg] = sT[p][cl];
-            }
-    }
-    if (anyCol) {
-        // columns of S: (X_0 Gamma)[r][q] = sum_p X_0^T[p][r] Gamma[p][q]; formed as D[q][r] with A[i = q][k = p] = Gamma[p][q]
-        __syncthreads();
-        for (int e = tid; e < WIMG; e += 256) sM[e] = acc_set[WSM_GAM + e];
-        __syncthreads();
-        v4d acc[4];
-#pragma unroll
-        for (int qi = 0; qi < 4; qi++) acc[qi] = v4d{0.0, 0.0, 0.0, 0.0};
-        for (int p0 = 0; p0 < 64; p0 += 4) {
-            const double b = sX[p0 + lk][16 * wave + li];                                                   // B[k = p][j = r]
-#pragma unroll
-            for (int qi = 0; qi < 4; qi++) acc[qi] = __builtin_amdgcn_mfma_f64_16x16x4f64(sM[(p0 + lk) * WS + 16 * qi + li], b, acc[qi], 0, 0, 0);
-        }
-#pragma unroll
-        for (int qi = 0; qi < 4; qi++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) sT[16 * qi + lk + 4 * reg][16 * wave + li] = acc[qi][reg];     // sT[q][row]
-        __syncthreads();
-#pragma unroll
-        for (int ri = 0; ri < 4; ri++)
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int cl = 16 * wave + lk + 4 * reg, rl = 16 * ri + li;
-                const int q = sColPos[cl];
-                if (q >= 0) {
-                    const int p = sRowPos[rl];
-                    sig[ri][reg] = p >= 0 ? small[WSM_P + p * WS + q] : sT[q][rl];
-                }
-            }
-    }
-#pragma unroll
-    for (int ri = 0; ri < 4; ri++)
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int c = c0 + 16 * wave + lk + 4 * reg, r = r0 + 16 * ri + li;
-            if (r < N && c < N) E.d_sigma[(size_t)c * ld + r] = sig[ri][reg];
-        }
-    if (blockIdx.y == 0 && tid < 64 && r0 + tid < N && sRowPos[tid] < 0) {
-        double acc = 0;
-        for (int p = 0; p < s; p++) acc += sX[p][tid] * acc_set[WSM_psi + p];
-        E.d_mu[r0 + tid] += acc;                                   // mu_R += X_0 psi
+    if (tid < 64 && c0 + tid < N && E.d_win_sidx[c0 + tid] < 0) E.d_mu[c0 + tid] += macc;      // mu_R += Y_0^T psi
+}
+
+// Rows and columns S of Sigma after the Z pass: row S_p <- Y_K[p][:], column S_p <- the same (symmetry), (S_p, S_q) <- P_K[p][q].
+__global__ __launch_bounds__(256) void k_ekf_win_fix(EkfState E, WinDesc wd, int SP) {
+    const int ld = E.ld;
+    const int N = 3 + 3 * (*E.d_L);
+    const int s = 3 + 3 * wd.nS;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N) return;
+    const int tp = E.d_win_sidx[t];
+    const double* Pimg = E.d_win_small + wsm_P(E.win_sp_max);
+    for (int p = blockIdx.y; p < s; p += gridDim.y) {
+        const int Sp = win_state_index(wd, p);
+        const double v = tp >= 0 ? Pimg[(size_t)p * SP + tp] : E.d_V[(size_t)p * ld + t];
+        E.d_sigma[(size_t)Sp * ld + t] = v;                        // column S_p, row t (coalesced)
+        if (tp < 0) E.d_sigma[(size_t)t * ld + Sp] = v;            // row S_p, column t
     }
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
-void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs,
-                          const unsigned* n_markers, const double* enc, const unsigned char* d_obs_idx) {
-    const int ngather = (E.ld + WCT - 1) / WCT;
-    hipLaunchKernelGGL(k_ekf_win_chain, dim3(1 + ngather), dim3(WCT), 0, st, E, sp, wd, obs, n_markers, enc, d_obs_idx);
+void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc) {
+    const int nt = wd.T == 12 ? 448 : 320;
+    const int ngather = wd.piece == 0 ? (E.ld + nt - 1) / nt : 0;
+    if (wd.T == 4) hipLaunchKernelGGL((k_ekf_win_chain<4, 1>), dim3(1 + ngather), dim3(320), 0, st, E, sp, wd, obs, enc);
+    else if (wd.T == 8) hipLaunchKernelGGL((k_ekf_win_chain<8, 2>), dim3(1 + ngather), dim3(320), 0, st, E, sp, wd, obs, enc);
+    else hipLaunchKernelGGL((k_ekf_win_chain<12, 2>), dim3(1 + ngather), dim3(448), 0, st, E, sp, wd, obs, enc);
 }
-void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd) {
-    hipLaunchKernelGGL(k_ekf_win_scan, dim3(4, 4), dim3(256), 0, st, E, wd);
+void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd, int nsteps) {
+    if (wd.T == 4) {
+        hipLaunchKernelGGL(k_ekf_win_scan<4>, dim3(4), dim3(256), 0, st, E, wd, nsteps);
+        hipLaunchKernelGGL(k_ekf_win_psi<4>, dim3(4), dim3(256), 0, st, E, wd, nsteps);
+    } else if (wd.T == 8) {
+        hipLaunchKernelGGL(k_ekf_win_scan<8>, dim3(8), dim3(256), 0, st, E, wd, nsteps);
+        hipLaunchKernelGGL(k_ekf_win_psi<8>, dim3(8), dim3(256), 0, st, E, wd, nsteps);
+    } else {
+        hipLaunchKernelGGL(k_ekf_win_scan<12>, dim3(12), dim3(256), 0, st, E, wd, nsteps);
+        hipLaunchKernelGGL(k_ekf_win_psi<12>, dim3(12), dim3(256), 0, st, E, wd, nsteps);
+    }
 }
 void launch_ekf_win_flush(hipStream_t st, const EkfState& E, const WinDesc& wd) {
-    const int t = (E.ld + 63) / 64;
-    hipLaunchKernelGGL(k_ekf_win_flush, dim3(t, t), dim3(256), 0, st, E, wd);
+    const int SP = 16 * wd.T;
+    const int nb = (E.ld + 63) / 64;
+    if (wd.T == 4) hipLaunchKernelGGL(k_ekf_win_thin<4>, dim3(nb), dim3(256), 0, st, E, wd);
+    else if (wd.T == 8) hipLaunchKernelGGL(k_ekf_win_thin<8>, dim3(nb), dim3(256), 0, st, E, wd);
+    else hipLaunchKernelGGL(k_ekf_win_thin<12>, dim3(nb), dim3(256), 0, st, E, wd);
+    launch_ekf_update_mfma(st, E, SP);                            // Sigma -= Y_0^T U (d_Wt = Y_0, d_T = U), rows / columns S included
+    hipLaunchKernelGGL(k_ekf_win_fix, dim3((E.ld + 255) / 256, 16), dim3(256), 0, st, E, wd, SP);
 }
 
 } // namespace aslam

@@ -1,5 +1,6 @@
-"""Windowed EKF (aruco_slam_amd/csrc/ekf_window.hip): runs of frames that fuse the same landmarks are processed on the
-S x S block (chain kernel), the rest of Sigma follows once per window through Lambda / Gamma / Psi (scan + flush kernels).
+"""Windowed EKF (aruco_slam_amd/csrc/ekf_window.hip): runs of frames whose fused landmarks fit into one set S are processed on the
+S x S block (chain kernel: the reference's sequential rank-3 corrections on the matrix cores), the rest of Sigma follows once per
+window through Lambda / Psi (scan + flush kernels).  Frames of a window may fuse any subset of S and drop "stationary" observations.
 Observation sequences are injected (no detector) and every batch is compared with the numpy LITERAL transcription of the
 reference (oracle/ekf_literal.py: dense matrices exactly as aruco_slam.cpp:21-74, 88-263 forms them) and with the per-frame
 device chain (ASLAM_NO_WINDOWS).  Runs on the emulation build here and on the real library on the MI355X box."""
@@ -54,12 +55,13 @@ def make_case(seed, groups, n_land):
     return frames, exp
 
 
-def run_device(frames, exp, batch, windows=True, check=True, max_landmarks=40):
+def run_device(frames, exp, batch, windows=True, check=True, max_landmarks=40, max_updates=24):
     if not windows:
         os.environ["ASLAM_NO_WINDOWS"] = "1"
     try:
         nfr = len(frames)
-        ctx = capi.Context(max_rows=64, max_cols=64, max_batch=nfr, persistent_waves=4, max_landmarks=max_landmarks, r2c_t=(0.1, -0.05, 0.0))
+        ctx = capi.Context(max_rows=64, max_cols=64, max_batch=nfr, persistent_waves=4, max_landmarks=max_landmarks, r2c_t=(0.1, -0.05, 0.0),
+                           max_updates_per_frame=max_updates)
     finally:
         os.environ.pop("ASLAM_NO_WINDOWS", None)
     ctx.set_camera(K, D)
@@ -98,13 +100,22 @@ def run_device(frames, exp, batch, windows=True, check=True, max_landmarks=40):
 CASES = {
     # one long run on the same 6 landmarks; a second group of other landmarks; back to a mix (pose rows in the middle of the state)
     "two_groups": (1, [(9, [0, 1, 2, 3, 4, 5], False), (8, [6, 7, 8], False), (7, [1, 4, 7, 9, 10], False)], 11),
-    # 20 landmarks per frame: the largest window the chain kernel takes (s = 63)
+    # 20 landmarks per frame, two sets whose union (25) needs the 128-wide image
     "full_width": (2, [(6, list(range(20)), False), (5, list(range(5, 25)), False)], 25),
-    # a repeated pose inside a run: the "stationary" no-op branch cuts the window
-    "stationary_cut": (3, [(4, [0, 1, 2, 3], False), (3, [0, 1, 2, 3], True), (5, [0, 1, 2, 3], False)], 4),
+    # a repeated pose inside a run: the "stationary" no-op drops out of its frame, the window goes on
+    "stationary_inside": (3, [(4, [0, 1, 2, 3], False), (3, [0, 1, 2, 3], True), (5, [0, 1, 2, 3], False)], 4),
     # a single landmark (s = 6) and a long window (more frames than one window holds: 64)
     "one_landmark_long": (4, [(3, [0, 1, 2], False), (70, [1], False)], 3),
+    # frames that see SUBSETS of the window's set (a marker lost to the detector or to a gate), in changing combinations
+    "subset_frames": (5, [(3, list(range(8)), False), (3, [1, 3, 5], False), (2, [0, 2, 4, 6, 7], False), (1, [7], False), (3, list(range(8)), False)], 8),
+    # a visible set that slides by one landmark per frame: the union of a window grows past 20 landmarks (128-wide image)
+    "sliding_set": (6, [(1, list(range(12)), False), (1, list(range(12, 24)), False), (1, list(range(24, 30)), False)]
+                    + [(1, list(range(i, i + 12)), False) for i in range(0, 19)], 30),
+    # a frame without any observation inside a run (predict only)
+    "empty_frame": (7, [(3, [0, 1, 2], False), (2, [], False), (3, [0, 2], False)], 3),
 }
+# 50 corrections per frame on 55 landmarks (BASELINE config 3's width): the 192-wide image, 6 worker waves
+WIDE = (8, [(3, list(range(50)), False), (3, list(range(5, 55)), False)], 55)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -132,6 +143,36 @@ def test_scan_continuation_pieces_read_the_previous_piece(piece, monkeypatch):
         run_device(frames, exp, batch=len(frames))
 
 
+def test_wide_window_50_corrections_per_frame():
+    seed, groups, n_land = WIDE
+    frames, exp = make_case(seed, groups, n_land)
+    (mu, S), prof, worst = run_device(frames, exp, batch=len(frames), max_landmarks=60, max_updates=64)
+    assert prof["k_ekf_win_chain"][0] > 0, "no window was formed"
+
+
+def test_windows_really_cover_subsets_and_sliding_sets():
+    """the planner must keep such frames INSIDE windows (not fall back to the per-frame chain)"""
+    for name in ("subset_frames", "sliding_set", "stationary_inside", "empty_frame"):
+        seed, groups, n_land = CASES[name]
+        frames, exp = make_case(seed, groups, n_land)
+        nfr = len(frames)
+        ctx = capi.Context(max_rows=64, max_cols=64, max_batch=nfr, persistent_waves=4, max_landmarks=40, r2c_t=(0.1, -0.05, 0.0))
+        ctx.set_camera(K, D)
+        t = [fr["t"] for fr in frames]
+        ctx.stage_encoders([fr["wl"] for fr in frames], [fr["wr"] for fr in frames], [0.0] + [t[i] - t[i - 1] for i in range(1, nfr)])
+        for f, fr in enumerate(frames):
+            obs = fr["obs"]
+            ctx.inject_observations(f, fr["ids"], [0 if o is None else 1 for o in obs],
+                                    np.array([np.zeros(3) if o is None else o["z"] for o in obs]).reshape(-1, 3),
+                                    np.array([np.ones(3) if o is None else np.diag(o["R"]) for o in obs]).reshape(-1, 3))
+        ctx.profile_reset()
+        ctx.run_staged(0, nfr, with_ekf=2)
+        ctx.sync()
+        ps = ctx.plan_stats()
+        n_aug = sum(1 for e in exp if (e["log"][:, 2] == 0).any()) if name != "empty_frame" else 1
+        assert ps["frames_in_windows"] >= nfr - n_aug - 2, (name, ps, n_aug)
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5])
 def test_windows_with_small_batches(batch):
     """windows never span calls: any batching gives the reference's result after every call"""
@@ -148,6 +189,27 @@ def test_windows_on_gpu(name):
     (mu, S), prof, worst = run_device(frames, exp, batch=len(frames))
     assert prof["k_ekf_win_chain"][0] > 0
     run_device(frames, exp, batch=3)
+
+
+@pytest.mark.gpu
+def test_wide_window_on_gpu():
+    seed, groups, n_land = WIDE
+    frames, exp = make_case(seed, groups, n_land)
+    (mu, S), prof, worst = run_device(frames, exp, batch=len(frames), max_landmarks=60, max_updates=64)
+    assert prof["k_ekf_win_chain"][0] > 0
+    run_device(frames, exp, batch=4, max_landmarks=60, max_updates=64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("piece", [1, 2, 3])
+def test_chain_pieces_on_gpu(piece, monkeypatch):
+    """the piece hand-over (P image, Lambda blocks, psi, Psi tiles carried through global memory between launches) on the device,
+    with short pieces and a second window that drops landmarks of the first"""
+    monkeypatch.setenv("ASLAM_WIN_PIECE", str(piece))
+    for groups in ([(6, list(range(10)), False), (5, list(range(5, 15)), False)],
+                   [(6, list(range(20)), False), (5, list(range(5, 20)), False)]):
+        frames, exp = make_case(2, groups, 25)
+        run_device(frames, exp, batch=len(frames))
 
 
 def test_restaging_slots_of_a_submitted_batch_does_not_reach_it():
