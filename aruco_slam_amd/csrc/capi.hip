@@ -26,6 +26,7 @@ using namespace aslam;
 
 namespace {
 
+constexpr int kWinWidenFrames = 16;     // a window of at least this many frames is not widened to the next image size (64 -> 128 -> 192)
 constexpr int kWinLastPiece = 2;        // frames of a run's last chain piece (its scan and the flush are what the next window waits for)
 constexpr int kWinChainFrames = 8;      // frames per chain kernel of a window (its log is replayed meanwhile); <= kWinPieceMax
 
@@ -810,7 +811,9 @@ int finalize_pending(aslam_ctx* c) {
         // does the frame fit into the open window?  (its landmarks are ascending, like S)
         std::vector<int> un;
         if (w_K > 0) std::set_union(w_S.begin(), w_S.end(), fp.corr_idx.begin(), fp.corr_idx.end(), std::back_inserter(un));
-        if (w_K == 0 || w_K >= kWinFrames || (int)un.size() > s_cap || f != w_first + w_K) {
+        // a wider image makes every step of the window dearer: a window that is already long is closed rather than widened
+        const bool widens = w_K >= kWinWidenFrames && ekf_win_tiles((int)un.size()) > ekf_win_tiles((int)w_S.size());
+        if (w_K == 0 || w_K >= kWinFrames || (int)un.size() > s_cap || f != w_first + w_K || widens) {
             close_window();
             w_first = f; w_K = 0;
             un = fp.corr_idx;

@@ -39,7 +39,14 @@
 
 namespace aslam {
 
-constexpr int WBW = 16;                       // columns of Lambda per scan workgroup
+constexpr int WBW = 8;                        // columns of Lambda per scan workgroup
+
+// development aid (make FLAGS+=-DASLAM_WIN_STAMPS): cycle stamps of the prepare wave's step phases and of the workers, summed over a piece
+#ifdef ASLAM_WIN_STAMPS
+#define WSTAMP(i) do { const long long t_ = clock64(); stamp_acc[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
 
 __host__ __device__ inline int win_log_stride(int T) { return 3 * 16 * T + kWinHdr; }
 __host__ __device__ inline int win_tlog_stride(int T) { return 8 * 16 * T; }
@@ -65,6 +72,15 @@ template <int NC> __device__ __forceinline__ double bcast_at(const double (&v)[N
     if (NC > 1) { const double r1 = ASLAM_WAVE_BCAST(v[NC > 1 ? 1 : 0], ln); r = ch == 1 ? r1 : r; }
     if (NC > 2) { const double r2 = ASLAM_WAVE_BCAST(v[NC > 2 ? 2 : 0], ln); r = ch == 2 ? r2 : r; }
     return r;
+}
+
+// the same with the chunk selected by uniform conditional moves in front of ONE cross-lane read (idx wave-uniform, every lane calls)
+template <int NC> __device__ __forceinline__ double bcast_sel(const double (&v)[NC], int idx) {
+    const int ch = idx >> 6;
+    double x = v[0];
+    if (NC > 1) x = ch == 1 ? v[NC > 1 ? 1 : 0] : x;
+    if (NC > 2) x = ch == 2 ? v[NC > 2 ? 2 : 0] : x;
+    return ASLAM_WAVE_BCAST(x, idx & 63);
 }
 
 // Rows p .. p + 2 of the image leave the accumulators of the worker wave(s) that own them (row r = 16 g + lk + 4 reg of tile row
@@ -182,7 +198,11 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
         }
         if (NS > 1 && sPos[1] != 255) win_publish<T, RW>(acc, 3 + 3 * sPos[1], wave, lk, li, &sPub[1][3][0], SPP);
         ASLAM_LDS_BARRIER();
+#ifdef ASLAM_WIN_STAMPS
+        long long stamp_acc[4] = {0, 0, 0, 0}, stamp_last = clock64();
+#endif
         for (int j = -1; j < NS; j++) {
+            WSTAMP(0);
             if (j >= 0) {
                 const int cb = j & 1;
                 double b[T];
@@ -207,8 +227,12 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
                     if (pn != 255) win_publish<T, RW>(acc, 3 + 3 * pn, wave, lk, li, &sPub[cb][3][0], SPP);
                 }
             }
+            WSTAMP(1);
             ASLAM_LDS_BARRIER();
         }
+#ifdef ASLAM_WIN_STAMPS
+        if (lane == 0 && wd.piece == 1) printf("worker %d T %d steps %d: barrier-wait %lld work %lld cycles per step\n", wave, T, NS, stamp_acc[0] / (NS + 1), stamp_acc[1] / (NS + 1));
+#endif
         // P_K for the next piece / the flush
         double* Pout = E.d_win_small + wsm_P(E.win_sp_max);
 #pragma unroll
@@ -221,61 +245,80 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
     }
 
     // ======================================= prepare wave: lane = column (NC chunks of 64) =======================================
-    double mu[NC], pA[4][NC], pB[4][NC];
+    // What a step needs from another column (the previous step's A operand at the six row indices, c at the six special columns)
+    // is wave-uniform and is read back from LDS as a broadcast - the operands live there anyway (measured: cheaper than v_readlane
+    // plus chunk selection).
+    const double kl = sp.kl, kr = sp.kr, inv2b = 1.0 / (2 * sp.b), invb = 1 / sp.b, Qk = sp.Q_k;
+    double* const logbase = E.d_win_log + (size_t)wd.log0 * win_log_stride(T);
+    double mu[NC], pB[4][NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const int col = lane + 64 * c;
         mu[c] = col < s ? E.d_mu[sS[col]] : 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { pA[k][c] = 0.0; pB[k][c] = 0.0; }
+        for (int k = 0; k < 4; k++) pB[k][c] = 0.0;
     }
     // per-frame records, lane a = correction a of the frame (aruco_slam.cpp:119-143 at the frozen mean)
     double rze0 = 0, rze1 = 0, rze2 = 0, rR0 = 0, rR1 = 0, rR2 = 0, rg02 = 0, rg12 = 0;
     double cth = 1.0, sth = 0.0;
+    bool prev_predict = false;
+    bool dirty0 = false, dirty1 = false;                           // operand buffer 0 / 1 holds a predict's fourth depth row
     // the first frame's inputs
     ObsRaw nObs{};
-    {
-        const WinFrame& fr = frames[wd.first_slot];
-        if (lane < fr.m) nObs = obs[(size_t)wd.first_slot * kMarkerMax + fr.cdet[lane]];
-    }
+    if (lane < sOff[1] - 1) nObs = obs[(size_t)wd.first_slot * kMarkerMax + frames[wd.first_slot].cdet[lane]];
     double e_wl, e_wr, e_dt;
     { const double* e = enc + (size_t)3 * wd.first_slot; e_wl = e[0]; e_wr = e[1]; e_dt = e[2]; }
     ASLAM_LDS_BARRIER();                                           // (pairs with the workers' barrier after their first publish)
+#ifdef ASLAM_WIN_STAMPS
+    long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = clock64();
+    int n_pred = 0;
+#endif
     for (int j = -1; j < NS; j++) {
         const int n = j + 1;                                       // the step prepared in this phase
+        WSTAMP(0);
         if (n < NS) {
-            const int nb = n & 1;
+            const int nb = n & 1, pb = j & 1;
             const int pos = sPos[n];
             const bool is_predict = pos == 255;
-            const int k = sFrm[n];
-            const int slot = wd.first_slot + k;
-            const int lrow = is_predict ? 0 : 3 + 3 * pos;         // first landmark row
+            const int lrow = is_predict ? 0 : 3 + 3 * pos;         // first landmark row (a predict has none: copies of the pose rows)
             double r[6][NC];
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
                 for (int c = 0; c < NC; c++) r[i][c] = sPub[nb][i][lane + 64 * c];
             if (j >= 0) {
-                // step j's correction of these rows: P[R][col] += sum_k Aop_j[k][R] Bop_j[k][col], from the registers
+                // step j's correction of these rows: P[R][col] += sum_k Aop_j[k][R] Bop_j[k][col]
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const int R = i < 3 ? i : lrow + (i - 3);       // (a predict step has no landmark rows: rows 3..5 are then unused copies of the pose rows)
+                for (int kk = 0; kk < 4; kk++) {
+                    if (kk == 3 && !prev_predict) break;            // a correction has depth 3
+                    const double f0 = sA[pb][kk][0], f1 = sA[pb][kk][1], f2 = sA[pb][kk][2];      // (LDS broadcast reads: measured faster than v_readlane)
+                    const double f3 = sA[pb][kk][lrow], f4 = sA[pb][kk][lrow + 1], f5 = sA[pb][kk][lrow + 2];
 #pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const double f = bcast_at<NC>(pA[kk], R);
-#pragma unroll
-                        for (int c = 0; c < NC; c++) r[i][c] = fma(f, pB[kk][c], r[i][c]);
+                    for (int c = 0; c < NC; c++) {
+                        r[0][c] = fma(f0, pB[kk][c], r[0][c]); r[1][c] = fma(f1, pB[kk][c], r[1][c]); r[2][c] = fma(f2, pB[kk][c], r[2][c]);
+                        r[3][c] = fma(f3, pB[kk][c], r[3][c]); r[4][c] = fma(f4, pB[kk][c], r[4][c]); r[5][c] = fma(f5, pB[kk][c], r[5][c]);
                     }
                 }
             }
-            double* log = E.d_win_log + (size_t)(wd.log0 + n) * win_log_stride(T);
+            WSTAMP(1);
+            double* log = logbase + (size_t)n * win_log_stride(T);
+            double* hdr = log + 3 * SP;
             double A[4][NC], B[4][NC];
             if (is_predict) {
+#ifdef ASLAM_WIN_STAMPS
+                n_pred++;
+#endif
+                const int k = sFrm[n];
+                const int slot = wd.first_slot + k;
+                const int fm = sOff[k + 1] - sOff[k] - 1;           // corrections of the frame
                 // ---- predict (aruco_slam.cpp:35-73) with the final mean of the previous frame ----
-                const double delta_sl = sp.kl * (e_dt * e_wl), delta_sr = sp.kr * (e_dt * e_wr);
-                const double delta_theta = (delta_sr - delta_sl) / (2 * sp.b);
+                const double delta_sl = kl * (e_dt * e_wl), delta_sr = kr * (e_dt * e_wr);
+                const double delta_theta = (delta_sr - delta_sl) * inv2b;
                 const double delta_s = 0.5 * (delta_sr + delta_sl);
-                const double m0 = ASLAM_WAVE_BCAST(mu[0], 0), m1 = ASLAM_WAVE_BCAST(mu[0], 1), m2 = ASLAM_WAVE_BCAST(mu[0], 2);
+#pragma unroll
+                for (int c = 0; c < NC; c++) sMu[lane + 64 * c] = mu[c];
+                __builtin_amdgcn_wave_barrier();
+                const double m0 = sMu[0], m1 = sMu[1], m2 = sMu[2];
                 double th = m2 + delta_theta;
                 wrap1(th);
                 // the two sincos of the frame in one call: even lanes the mid-step heading, odd lanes the new heading
@@ -284,34 +327,32 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
                 const double cm = ASLAM_WAVE_BCAST(cv, 0), sm = ASLAM_WAVE_BCAST(sv, 0);
                 cth = ASLAM_WAVE_BCAST(cv, 1); sth = ASLAM_WAVE_BCAST(sv, 1);
                 const double ua = -delta_s * sm, ub = delta_s * cm;                 // H3 = I + [ua ub 0]^T e2^T
-                const double f = 0.5 * sp.kl * e_dt;                                 // kl for BOTH wheels (quirk Q7)
-                const double su0 = sp.Q_k * fabs(e_wl), su1 = sp.Q_k * fabs(e_wr);
+                const double f = 0.5 * kl * e_dt;                                    // kl for BOTH wheels (quirk Q7)
+                const double su0 = Qk * fabs(e_wl), su1 = Qk * fabs(e_wr);
                 const double P22 = ASLAM_WAVE_BCAST(r[2][0], 2);
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     const int col = lane + 64 * c;
                     const double u = col == 0 ? ua : col == 1 ? ub : 0.0;
-                    const double w0 = col == 0 ? f * cm : col == 1 ? f * sm : col == 2 ? f * (1 / sp.b) : 0.0;      // wkh column 0
-                    const double w1 = col == 0 ? f * cm : col == 1 ? f * sm : col == 2 ? f * (-1 / sp.b) : 0.0;     // wkh column 1
+                    const double w0 = col == 0 ? f * cm : col == 1 ? f * sm : col == 2 ? f * invb : 0.0;        // wkh column 0
+                    const double w1 = col == 0 ? f * cm : col == 1 ? f * sm : col == 2 ? f * -invb : 0.0;       // wkh column 1
                     A[0][c] = u;                       B[0][c] = r[2][c];
                     A[1][c] = fma(P22, u, r[2][c]);    B[1][c] = u;
                     A[2][c] = su0 * w0;                B[2][c] = w0;
                     A[3][c] = su1 * w1;                B[3][c] = w1;
+                    sA[nb][3][col] = A[3][c]; sB[nb][3][col] = B[3][c];
                 }
-                if (lane == 0) mu[0] = m0 + delta_s * cm;
-                if (lane == 1) mu[0] = m1 + delta_s * sm;
+                if (nb) dirty1 = true; else dirty0 = true;
+                const double np0 = m0 + delta_s * cm, np1 = m1 + delta_s * sm;
+                if (lane == 0) mu[0] = np0;
+                if (lane == 1) mu[0] = np1;
                 if (lane == 2) mu[0] = th;
                 // ---- the frame's records at the frozen mean (pose just predicted, landmarks as the previous frame left them) ----
-                const WinFrame& fr = frames[slot];
-#pragma unroll
-                for (int c = 0; c < NC; c++) sMu[lane + 64 * c] = mu[c];
-                __builtin_amdgcn_wave_barrier();
-                if (lane < fr.m) {
-                    const int q = 3 + 3 * fr.cpos[lane];
-                    const double mu0x = sMu[0], mu0y = sMu[1], mu0t = sMu[2];
+                if (lane < fm) {
+                    const int q = 3 + 3 * sPos[sOff[k] + 1 + lane];
                     const double mx = sMu[q], my = sMu[q + 1], mth = sMu[q + 2];
-                    const double gdx = mx - mu0x, gdy = my - mu0y;
-                    double gdth = mth - mu0t;
+                    const double gdx = mx - np0, gdy = my - np1;
+                    double gdth = mth - th;
                     wrap1(gdth);
                     const double zh0 = gdx * cth + gdy * sth, zh1 = -gdx * sth + gdy * cth;
                     double z2 = nObs.th - gdth;
@@ -321,13 +362,15 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
                     rR0 = nObs.r[0]; rR1 = nObs.r[1]; rR2 = nObs.r[2];
                 }
                 __builtin_amdgcn_wave_barrier();
+                const WinFrame& fr = frames[slot];
                 if (lane == 0 && slot < E.max_slots) {
                     int* st = E.d_slot_stat + 4 * slot;
-                    st[0] = fr.n_markers; st[1] = 0; st[2] = fr.m; st[3] = fr.npop - fr.m;
+                    st[0] = fr.n_markers; st[1] = 0; st[2] = fm; st[3] = fr.npop - fm;
                 }
                 if (wd.last && k == wd.K - 1) {
                     // what the window's last frame leaves behind for whatever follows: pop list, last_observed_marker_ (aruco_slam.cpp:202, 263)
-                    if (lane < fr.npop) {
+                    const int npop = fr.npop;
+                    if (lane < npop) {
                         const ObsRaw o = obs[(size_t)slot * kMarkerMax + fr.pdet[lane]];
                         const bool upd = fr.pact[lane] == 1;
                         PopRec pr;
@@ -341,24 +384,20 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
                         lo.z[0] = upd ? o.x : nanv; lo.z[1] = upd ? o.y : nanv; lo.z[2] = upd ? o.th : nanv;   // stationary: last_observation_ stays unset
                         E.d_last[lane] = lo;
                     }
-                    if (lane == 0) { *E.d_nlast = fr.npop; *E.d_npop = fr.npop; *E.d_m = fr.m; }
+                    if (lane == 0) { *E.d_nlast = npop; *E.d_npop = npop; *E.d_m = fm; }
                 }
                 // the next frame's inputs are fetched while this one is solved
                 if (k + 1 < wd.K) {
-                    const WinFrame& fn = frames[slot + 1];
-                    if (lane < fn.m) nObs = obs[(size_t)(slot + 1) * kMarkerMax + fn.cdet[lane]];
+                    const int fmn = sOff[k + 2] - sOff[k + 1] - 1;
+                    if (lane < fmn) nObs = obs[(size_t)(slot + 1) * kMarkerMax + frames[slot + 1].cdet[lane]];
                     const double* e = enc + (size_t)3 * (slot + 1);
                     e_wl = e[0]; e_wr = e[1]; e_dt = e[2];
                 }
-                if (lane < kWinHdr) {
-                    double hv = 0.0;
-                    if (lane == WH_POS) hv = -1.0;
-                    if (lane == WH_A) hv = ua;
-                    if (lane == WH_B) hv = ub;
-                    log[3 * SP + lane] = hv;
-                }
+                // header of the logged step: type 0, D's two entries, the frame's cos / sin (the corrections of the frame use them)
+                if (lane == 0) { hdr[WH_TYPE] = 0.0; hdr[WH_POS] = -1.0; hdr[WH_A] = ua; hdr[WH_B] = ub; hdr[WH_C] = cth; hdr[WH_S] = sth; }
+                WSTAMP(2);
             } else {
-                // ---- correction a of frame k: c = H P, S = c H^T + R, Kt = S^-1 c ----
+                // ---- correction a of the frame: c = H P, S = c H^T + R, Kt = S^-1 c ----
                 const int a = sIdx[n];
                 const double ze0 = ASLAM_WAVE_BCAST(rze0, a), ze1 = ASLAM_WAVE_BCAST(rze1, a), ze2 = ASLAM_WAVE_BCAST(rze2, a);
                 const double R0 = ASLAM_WAVE_BCAST(rR0, a), R1 = ASLAM_WAVE_BCAST(rR1, a), R2 = ASLAM_WAVE_BCAST(rR2, a);
@@ -370,23 +409,25 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
                     cc[0][c] = (-cth * r[0][c] - sth * r[1][c] + g02 * r[2][c]) + (cth * r[3][c] + sth * r[4][c]);
                     cc[1][c] = (sth * r[0][c] - cth * r[1][c] + g12 * r[2][c]) + (-sth * r[3][c] + cth * r[4][c]);
                     cc[2][c] = r[5][c] - r[2][c];
+                    sB[nb][0][lane + 64 * c] = cc[0][c]; sB[nb][1][lane + 64 * c] = cc[1][c]; sB[nb][2][lane + 64 * c] = cc[2][c];   // (the B operand, in place)
                 }
+                __builtin_amdgcn_wave_barrier();
+                WSTAMP(3);
                 double Sm[9], Si[9];
 #pragma unroll
                 for (int kk = 0; kk < 3; kk++) {
-                    const double p0 = ASLAM_WAVE_BCAST(cc[kk][0], 0), p1 = ASLAM_WAVE_BCAST(cc[kk][0], 1), p2 = ASLAM_WAVE_BCAST(cc[kk][0], 2);
-                    const double l0 = bcast_at<NC>(cc[kk], lrow), l1 = bcast_at<NC>(cc[kk], lrow + 1), l2 = bcast_at<NC>(cc[kk], lrow + 2);
+                    const double p0 = sB[nb][kk][0], p1 = sB[nb][kk][1], p2 = sB[nb][kk][2];
+                    const double l0 = sB[nb][kk][lrow], l1 = sB[nb][kk][lrow + 1], l2 = sB[nb][kk][lrow + 2];
                     Sm[kk * 3 + 0] = (-cth * p0 - sth * p1 + g02 * p2) + (cth * l0 + sth * l1);
                     Sm[kk * 3 + 1] = (sth * p0 - cth * p1 + g12 * p2) + (-sth * l0 + cth * l1);
                     Sm[kk * 3 + 2] = l2 - p2;
                 }
                 Sm[0] += R0; Sm[4] += R1; Sm[8] += R2;
                 inv3_fast(Sm, Si);
-                const double w0 = Si[0] * ze0 + Si[1] * ze1 + Si[2] * ze2, w1 = Si[3] * ze0 + Si[4] * ze1 + Si[5] * ze2,
-                             w2 = Si[6] * ze0 + Si[7] * ze1 + Si[8] * ze2;
+                WSTAMP(4);
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    // K = (P H^T) S^-1, (P H^T) = c^T:  Kt[k][col] = sum_k' c[k'][col] Si[k'][k]
+                    // K = (P H^T) S^-1, (P H^T) = c^T:  Kt[k][col] = sum_k' c[k'][col] Si[k'][k];  the A operand is -Kt
                     const double k0 = cc[0][c] * Si[0] + cc[1][c] * Si[3] + cc[2][c] * Si[6];
                     const double k1 = cc[0][c] * Si[1] + cc[1][c] * Si[4] + cc[2][c] * Si[7];
                     const double k2 = cc[0][c] * Si[2] + cc[1][c] * Si[5] + cc[2][c] * Si[8];
@@ -394,49 +435,60 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
                     A[0][c] = -k0; A[1][c] = -k1; A[2][c] = -k2; A[3][c] = 0.0;
                     B[0][c] = cc[0][c]; B[1][c] = cc[1][c]; B[2][c] = cc[2][c]; B[3][c] = 0.0;
                 }
-                (void)w0; (void)w1; (void)w2;
-                if (lane < kWinHdr) {
-                    double hv = 0.0;
-                    if (lane == WH_TYPE) hv = 1.0;
-                    if (lane == WH_POS) hv = (double)pos;
+                if (nb ? dirty1 : dirty0) {                         // the buffer last held a predict's fourth depth row
 #pragma unroll
-                    for (int q = 0; q < 9; q++) if (lane == WH_SI + q) hv = Si[q];      // (static register numbers: no scratch array)
-                    if (lane == WH_ZE) hv = ze0;
-                    if (lane == WH_ZE + 1) hv = ze1;
-                    if (lane == WH_ZE + 2) hv = ze2;
-                    if (lane == WH_C) hv = cth;
-                    if (lane == WH_S) hv = sth;
-                    if (lane == WH_G02) hv = g02;
-                    if (lane == WH_G12) hv = g12;
-                    log[3 * SP + lane] = hv;
+                    for (int c = 0; c < NC; c++) { sA[nb][3][lane + 64 * c] = 0.0; sB[nb][3][lane + 64 * c] = 0.0; }
+                    if (nb) dirty1 = false; else dirty0 = false;
                 }
+                // header of the logged step, stored by the lanes that hold the values
+                if (lane == 0) {
+                    hdr[WH_TYPE] = 1.0; hdr[WH_POS] = (double)pos;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) hdr[WH_SI + q] = Si[q];
+                }
+                if (lane == a) { hdr[WH_ZE] = rze0; hdr[WH_ZE + 1] = rze1; hdr[WH_ZE + 2] = rze2; hdr[WH_G02] = rg02; hdr[WH_G12] = rg12; }
+                WSTAMP(5);
             }
+            // operands to the workers, the log, and this wave's own copy
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++)
+            for (int c = 0; c < NC; c++) {
+                const int col = lane + 64 * c;
+                sA[nb][0][col] = A[0][c]; sA[nb][1][col] = A[1][c]; sA[nb][2][col] = A[2][c];
+                if (is_predict) { sB[nb][0][col] = B[0][c]; sB[nb][1][col] = B[1][c]; sB[nb][2][col] = B[2][c]; }
+                log[col] = A[0][c]; log[SP + col] = A[1][c]; log[2 * SP + col] = A[2][c];
 #pragma unroll
-                for (int c = 0; c < NC; c++) {
-                    sA[nb][kk][lane + 64 * c] = A[kk][c];
-                    sB[nb][kk][lane + 64 * c] = B[kk][c];
-                    pA[kk][c] = A[kk][c]; pB[kk][c] = B[kk][c];
-                    if (kk < 3) log[kk * SP + lane + 64 * c] = A[kk][c];
-                }
+                for (int kk = 0; kk < 4; kk++) pB[kk][c] = B[kk][c];
+            }
+            prev_predict = is_predict;
+            WSTAMP(6);
         }
         ASLAM_LDS_BARRIER();
     }
+#ifdef ASLAM_WIN_STAMPS
+    if (lane == 0 && wd.piece == 1) {
+        const int nc = NS - n_pred;
+        printf("prepare T %d steps %d (%d predict): barrier %lld | rows+correct %lld | predict path %lld per predict | c %lld S+inv %lld Kt+hdr %lld per correction | operands+log %lld per step\n",
+               T, NS, n_pred, stamp_acc[0] / (NS + 1), stamp_acc[1] / NS, stamp_acc[2] / (n_pred ? n_pred : 1), stamp_acc[3] / (nc ? nc : 1), stamp_acc[4] / (nc ? nc : 1),
+               stamp_acc[5] / (nc ? nc : 1), stamp_acc[6] / NS);
+    }
+#endif
     // ---- mu_S in place ----
 #pragma unroll
     for (int c = 0; c < NC; c++) { const int col = lane + 64 * c; if (col < s) E.d_mu[sS[col]] = mu[c]; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Replay of a piece's log on Lambda: workgroup b carries columns 16 b .. 16 b + 15 (all SP rows) and its entries of psi.
-// Per step: t = H Lambda (3 x 16), u = S^-1 t, Lambda += Aop^T t, psi += t^T (S^-1 ze); t and u are logged for the Psi product.
+// Replay of a piece's log on Lambda: workgroup b carries columns WBW b .. WBW b + WBW - 1 (all SP rows; in LDS) and its entries of psi.
+// Per step: t = H Lambda (3 x WBW), Lambda += Aop^T t, psi += t^T (S^-1 ze); t and u = S^-1 t are logged for the Psi product.
+// Two LDS barriers per step.  Wave 0 forms t (and then u, for the log) and is the only wave that stores, waves 1..3 are the only
+// ones that load (the next step's record, one step ahead): no wave ever waits for its own stores to be acknowledged.
 template <int T>
 __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd, int nsteps) {
-    constexpr int SP = 16 * T, EPT = SP * WBW / 256;              // Lambda entries per thread
+    constexpr int SP = 16 * T, EPT = SP * WBW / 256, REC = 3 * SP + kWinHdr;
+    constexpr int RPT = (REC + 191) / 192;                         // record doubles per loading thread
     __shared__ double sLam[SP][WBW + 1];
-    __shared__ double sRec[2][3 * SP + kWinHdr];
-    __shared__ double sT[4][WBW], sU[4][WBW];
+    __shared__ double sRec[2][REC];
+    __shared__ double sT[2][4][WBW];                               // t (row 3 stays zero)
     const int tid = threadIdx.x, b = blockIdx.x;
     const int ls = win_log_stride(T), ts = win_tlog_stride(T);
     double* Lam = E.d_win_small + wsm_LAM(E.win_sp_max);
@@ -445,74 +497,88 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd, in
         const int r = e / WBW, c = e % WBW;
         sLam[r][c] = wd.piece ? Lam[(size_t)r * SP + WBW * b + c] : (r == WBW * b + c ? 1.0 : 0.0);
     }
-    double ps = (tid < WBW && wd.piece) ? psi[WBW * b + tid] : 0.0;
+    double ps = (tid >= 4 * WBW && tid < 5 * WBW && wd.piece) ? psi[WBW * b + tid - 4 * WBW] : 0.0;     // (the thread that accumulates entry c: below)
+    double cth = 1.0, sth = 0.0;
     const double* logp = E.d_win_log + (size_t)wd.log0 * ls;
-    double* tlog = E.d_win_tlog + (size_t)wd.log0 * ts;
-    constexpr int RPT = (3 * SP + kWinHdr + 255) / 256;           // record doubles per thread
+    double* tlog = E.d_win_tlog + (size_t)wd.log0 * ts + WBW * b;
+    const int lt = tid - 64;                                       // loading thread index (waves 1..3)
     double pf[RPT];
 #pragma unroll
-    for (int q = 0; q < RPT; q++) { const int e = tid + 256 * q; pf[q] = (e < 3 * SP + kWinHdr && nsteps > 0) ? logp[e] : 0.0; }
-    if (tid < 4 * WBW) { (&sT[0][0])[tid] = 0.0; (&sU[0][0])[tid] = 0.0; }
+    for (int q = 0; q < RPT; q++) { const int e = lt + 192 * q; pf[q] = (lt >= 0 && e < REC && nsteps > 0) ? logp[e] : 0.0; }
+    for (int e = tid; e < 2 * 4 * WBW; e += 256) (&sT[0][0][0])[e] = 0.0;
     __syncthreads();
     for (int n = 0; n < nsteps; n++) {
         double* rec = sRec[n & 1];
+        double (*tt)[WBW] = sT[n & 1];
+        if (lt >= 0) {
 #pragma unroll
-        for (int q = 0; q < RPT; q++) { const int e = tid + 256 * q; if (e < 3 * SP + kWinHdr) rec[e] = pf[q]; }
-        if (n + 1 < nsteps) {                                       // in flight while this step is applied
-            const double* nx = logp + (size_t)(n + 1) * ls;
+            for (int q = 0; q < RPT; q++) { const int e = lt + 192 * q; if (e < REC) rec[e] = pf[q]; }
+            if (n + 1 < nsteps) {                                   // in flight while this step is applied
+                const double* nx = logp + (size_t)(n + 1) * ls;
 #pragma unroll
-            for (int q = 0; q < RPT; q++) { const int e = tid + 256 * q; pf[q] = e < 3 * SP + kWinHdr ? nx[e] : 0.0; }
+                for (int q = 0; q < RPT; q++) { const int e = lt + 192 * q; pf[q] = e < REC ? nx[e] : 0.0; }
+            }
         }
         ASLAM_LDS_BARRIER();
         const double* hd = rec + 3 * SP;
-        if (hd[WH_TYPE] == 0.0) {
-            // predict: Lambda <- D Lambda (rows 0, 1 += (a, b) row 2); nothing for Psi / psi
-            if (tid < WBW) { sLam[0][tid] += hd[WH_A] * sLam[2][tid]; sLam[1][tid] += hd[WH_B] * sLam[2][tid]; }
-            if (tid < 8 * WBW) {                                    // t = u = 0 for this step
-                const int row = tid / WBW, c = tid % WBW;
-                tlog[(size_t)n * ts + row * SP + WBW * b + c] = 0.0;
-            }
-            ASLAM_LDS_BARRIER();
-            continue;
-        }
-        const int lrow = 3 + 3 * (int)hd[WH_POS];
+        const bool is_predict = hd[WH_TYPE] == 0.0;
         if (tid < WBW) {
             const int c = tid;
-            const double cth = hd[WH_C], sth = hd[WH_S], g02 = hd[WH_G02], g12 = hd[WH_G12];
-            const double r0 = sLam[0][c], r1 = sLam[1][c], r2 = sLam[2][c], l0 = sLam[lrow][c], l1 = sLam[lrow + 1][c], l2 = sLam[lrow + 2][c];
-            const double t0 = (-cth * r0 - sth * r1 + g02 * r2) + (cth * l0 + sth * l1);
-            const double t1 = (sth * r0 - cth * r1 + g12 * r2) + (-sth * l0 + cth * l1);
-            const double t2 = l2 - r2;
-            const double* Si = hd + WH_SI;
-            // u = S^-1 t (Z <- Z - (H Y)^T S^-1 (H Y));  psi += t^T (S^-1 ze)
-            const double u0 = Si[0] * t0 + Si[1] * t1 + Si[2] * t2, u1 = Si[3] * t0 + Si[4] * t1 + Si[5] * t2, u2 = Si[6] * t0 + Si[7] * t1 + Si[8] * t2;
-            const double z0 = hd[WH_ZE], z1 = hd[WH_ZE + 1], z2 = hd[WH_ZE + 2];
-            const double w0 = Si[0] * z0 + Si[1] * z1 + Si[2] * z2, w1 = Si[3] * z0 + Si[4] * z1 + Si[5] * z2, w2 = Si[6] * z0 + Si[7] * z1 + Si[8] * z2;
-            ps += t0 * w0 + t1 * w1 + t2 * w2;
-            sT[0][c] = t0; sT[1][c] = t1; sT[2][c] = t2;
-            sU[0][c] = u0; sU[1][c] = u1; sU[2][c] = u2;
+            if (is_predict) {
+                // Lambda <- D Lambda (rows 0, 1 += (a, b) row 2); nothing for Psi / psi
+                cth = hd[WH_C]; sth = hd[WH_S];                     // the frame's cos / sin (every piece starts with a predict)
+                const double r2 = sLam[2][c];
+                sLam[0][c] += hd[WH_A] * r2; sLam[1][c] += hd[WH_B] * r2;
+                tt[0][c] = 0.0; tt[1][c] = 0.0; tt[2][c] = 0.0;
+            } else {
+                const int lrow = 3 + 3 * (int)hd[WH_POS];
+                const double g02 = hd[WH_G02], g12 = hd[WH_G12];
+                const double r0 = sLam[0][c], r1 = sLam[1][c], r2 = sLam[2][c], l0 = sLam[lrow][c], l1 = sLam[lrow + 1][c], l2 = sLam[lrow + 2][c];
+                tt[0][c] = (-cth * r0 - sth * r1 + g02 * r2) + (cth * l0 + sth * l1);
+                tt[1][c] = (sth * r0 - cth * r1 + g12 * r2) + (-sth * l0 + cth * l1);
+                tt[2][c] = l2 - r2;
+            }
         }
         ASLAM_LDS_BARRIER();
         if (tid < 8 * WBW) {
-            const int row = tid / WBW, c = tid % WBW;
-            tlog[(size_t)n * ts + row * SP + WBW * b + c] = row < 4 ? sT[row][c] : sU[row - 4][c];
+            // the step's log rows of this block (wave 0): t (rows 0..2, row 3 zero), u = S^-1 t (rows 4..6, row 7 zero); psi += t^T (S^-1 ze)
+            const int row = tid / WBW, c = tid % WBW, k = row & 3;
+            const double t0 = tt[0][c], t1 = tt[1][c], t2 = tt[2][c];
+            double v = 0.0;
+            if (!is_predict && k < 3) {
+                const double* Si = hd + WH_SI + 3 * k;
+                v = row < 4 ? tt[k][c] : Si[0] * t0 + Si[1] * t1 + Si[2] * t2;     // (Z <- Z - (H Y)^T S^-1 (H Y))
+                if (row == 4) {                                     // thread (4, c): the whole of psi's entry c
+                    const double* S9 = hd + WH_SI;
+                    const double z0 = hd[WH_ZE], z1 = hd[WH_ZE + 1], z2 = hd[WH_ZE + 2];
+                    const double w0 = S9[0] * z0 + S9[1] * z1 + S9[2] * z2, w1 = S9[3] * z0 + S9[4] * z1 + S9[5] * z2, w2 = S9[6] * z0 + S9[7] * z1 + S9[8] * z2;
+                    ps += t0 * w0 + t1 * w1 + t2 * w2;
+                }
+            }
+            tlog[(size_t)n * ts + row * SP + c] = v;
         }
-        // Lambda[r][c] += sum_k Aop[k][r] t[k][c]
+        if (!is_predict) {
+            // Lambda[r][c] += sum_k Aop[k][r] t[k][c]      (c is the same for all of a thread's entries)
+            const int c = tid % WBW;
+            const double t0 = tt[0][c], t1 = tt[1][c], t2 = tt[2][c];
 #pragma unroll
-        for (int q = 0; q < EPT; q++) {
-            const int e = tid + 256 * q, r = e / WBW, c = e % WBW;
-            sLam[r][c] += rec[r] * sT[0][c] + rec[SP + r] * sT[1][c] + rec[2 * SP + r] * sT[2][c];
+            for (int q = 0; q < EPT; q++) {
+                const int r = (tid + 256 * q) / WBW;
+                sLam[r][c] += rec[r] * t0 + rec[SP + r] * t1 + rec[2 * SP + r] * t2;
+            }
         }
-        ASLAM_LDS_BARRIER();
     }
+    __syncthreads();
     for (int e = tid; e < SP * WBW; e += 256) { const int r = e / WBW, c = e % WBW; Lam[(size_t)r * SP + WBW * b + c] = sLam[r][c]; }
-    if (tid < WBW) psi[WBW * b + tid] = ps;
+    // psi's entry c was accumulated by thread (row 4, c) = tid 4 WBW + c
+    if (tid >= 4 * WBW && tid < 5 * WBW) psi[WBW * b + tid - 4 * WBW] = ps;
 }
 
 // Psi (+)= sum over the piece's steps of t^T u on the f64 matrix cores: workgroup = tile row, wave w = tile columns w, w + 4, ...
+// The operands come straight from the t / u log (L2): four steps are fetched ahead of the four products.
 template <int T>
 __global__ __launch_bounds__(256) void k_ekf_win_psi(EkfState E, WinDesc wd, int nsteps) {
-    constexpr int SP = 16 * T, TW = (T + 3) / 4;
+    constexpr int SP = 16 * T, TW = (T + 3) / 4, UN = 4;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int tr = blockIdx.x;
@@ -528,14 +594,20 @@ __global__ __launch_bounds__(256) void k_ekf_win_psi(EkfState E, WinDesc wd, int
             acc[q][reg] = (wd.piece && tc < T) ? Psi[(size_t)(16 * tr + lk + 4 * reg) * SP + 16 * tc + li] : 0.0;
     }
     // A[i][k] = t[k][16 tr + i] (lane k * 16 + i), B[k][j] = u[k][16 tc + j]
-    for (int n = 0; n < nsteps; n++) {
-        const double* st = tlog + (size_t)n * ts;
-        const double a = st[lk * SP + 16 * tr + li];
+    for (int n0 = 0; n0 < nsteps; n0 += UN) {
+        double a[UN], bv[UN][TW];
 #pragma unroll
-        for (int q = 0; q < TW; q++) {
-            const int tc = wave + 4 * q;
-            if (tc < T) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, st[(4 + lk) * SP + 16 * tc + li], acc[q], 0, 0, 0);
+        for (int u = 0; u < UN; u++) {
+            const bool ok = n0 + u < nsteps;
+            const double* st = tlog + (size_t)(ok ? n0 + u : n0) * ts;
+            a[u] = ok ? st[lk * SP + 16 * tr + li] : 0.0;
+#pragma unroll
+            for (int q = 0; q < TW; q++) { const int tc = wave + 4 * q; bv[u][q] = tc < T ? st[(4 + lk) * SP + 16 * tc + li] : 0.0; }
         }
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+#pragma unroll
+            for (int q = 0; q < TW; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], bv[u][q], acc[q], 0, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < TW; q++) {
@@ -625,13 +697,13 @@ void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& s
 }
 void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd, int nsteps) {
     if (wd.T == 4) {
-        hipLaunchKernelGGL(k_ekf_win_scan<4>, dim3(4), dim3(256), 0, st, E, wd, nsteps);
+        hipLaunchKernelGGL(k_ekf_win_scan<4>, dim3(64 / WBW), dim3(256), 0, st, E, wd, nsteps);
         hipLaunchKernelGGL(k_ekf_win_psi<4>, dim3(4), dim3(256), 0, st, E, wd, nsteps);
     } else if (wd.T == 8) {
-        hipLaunchKernelGGL(k_ekf_win_scan<8>, dim3(8), dim3(256), 0, st, E, wd, nsteps);
+        hipLaunchKernelGGL(k_ekf_win_scan<8>, dim3(128 / WBW), dim3(256), 0, st, E, wd, nsteps);
         hipLaunchKernelGGL(k_ekf_win_psi<8>, dim3(8), dim3(256), 0, st, E, wd, nsteps);
     } else {
-        hipLaunchKernelGGL(k_ekf_win_scan<12>, dim3(12), dim3(256), 0, st, E, wd, nsteps);
+        hipLaunchKernelGGL(k_ekf_win_scan<12>, dim3(192 / WBW), dim3(256), 0, st, E, wd, nsteps);
         hipLaunchKernelGGL(k_ekf_win_psi<12>, dim3(12), dim3(256), 0, st, E, wd, nsteps);
     }
 }

@@ -3,8 +3,8 @@
  *
  * The reference has no FFI layer; its boundary is the C++ class `ArucoSlam`
  * (include/aruco_slam/aruco_slam.h:101-193) whose headers drag in Eigen, OpenCV and ROS.  This header is
- * the POD-only surface a maintainer binds instead; include/aruco_slam/aruco_slam_hip.hpp wraps it in a
- * class with the reference's method names.  Every entry point cites the reference interface it replaces.
+ * the POD-only surface a maintainer binds instead; include/aruco_slam/aruco_slam.h wraps it in the
+ * reference's own class (same names and signatures).  Every entry point cites the reference interface it replaces.
  *
  * Conventions: every function returns 0 on success and a negative ASLAM_E_* code on failure (never
  * throws); aslam_last_error() gives the text.  A context is bound to one HIP device (it owns a few HIP streams there:
