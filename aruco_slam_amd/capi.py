@@ -135,6 +135,7 @@ _SIGS = {
     "aslam_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "aslam_profile_reset": (C.c_int, [C.c_void_p]),
     "aslam_get_plan_stats": (C.c_int, [C.c_void_p, _llp]),
+    "aslam_get_last_timing": (C.c_int, [C.c_void_p, _dp]),
     "aslam_profile_get": (C.c_int, [C.c_void_p, C.c_int, _P(C.c_char_p), _ip, _dp]),
     "aslam_synth_render": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, C.c_int, _ip, _dp, C.c_double, C.c_int,
                                      C.c_int, C.c_uint, C.c_int, _u8p]),
@@ -484,6 +485,12 @@ class Context:
 
     def profile_reset(self):
         self._ck(self.lib.aslam_profile_reset(self.h))
+
+    def last_timing(self):
+        """host-clock breakdown of the last add_image, microseconds"""
+        out = np.zeros(6)
+        self._ck(self.lib.aslam_get_last_timing(self.h, _ptr(out, _dp)))
+        return dict(zip(("upload", "enqueue_detect", "enqueue_ekf", "wait", "readback", "total"), out.tolist()))
 
     def plan_stats(self):
         """frames fused inside windows / on the per-frame chain, windows formed, frames left to the device's own plan (since profile_reset)"""

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cmath>
 #include <algorithm>
+#include <chrono>
 #include <iterator>
 
 using namespace aslam;
@@ -31,10 +32,10 @@ constexpr int kWinLastPiece = 2;        // frames of a run's last chain piece (i
 constexpr int kWinChainFrames = 8;      // frames per chain kernel of a window (its log is replayed meanwhile); <= kWinPieceMax
 
 enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
-              P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_EKF_MID64, P_EKF_WIN_CHAIN, P_EKF_WIN_SCAN, P_EKF_WIN_FLUSH, P_COUNT };
+              P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_EKF_MID64, P_EKF_WIN_CHAIN, P_EKF_WIN_SCAN, P_EKF_WIN_FLUSH, P_EKF_WIN_NEXT, P_COUNT };
 const char* kProfNames[P_COUNT] = {"k_threshold", "k_trace", "k_quads", "k_assemble", "k_identify", "k_pose",
                                    "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update_mfma", "k_ekf_mid", "k_ekf_apply",
-                                   "k_ekf_mid64", "k_ekf_win_chain", "k_ekf_win_scan", "k_ekf_win_flush"};
+                                   "k_ekf_mid64", "k_ekf_win_chain", "k_ekf_win_scan", "k_ekf_win_flush", "k_ekf_win_next"};
 
 struct ProfSpan { int id; hipEvent_t a, b; hipStream_t st; };
 
@@ -110,10 +111,12 @@ struct aslam_ctx {
     // behind the NEXT batch's detection, so that the detection stream never waits for the host
     bool win_enabled = true;
     int win_piece = kWinChainFrames;      // frames per chain piece (ASLAM_WIN_PIECE, 1..kWinChainFrames: a test knob)
+    bool win_no_early = false;            // ASLAM_WIN_NO_EARLY: every window waits for its own flush (test / comparison knob)
     struct Pending { bool active = false; int first = 0, count = 0, ev = 0; } pend;
     hipEvent_t ev_obs[2] = {nullptr, nullptr}, ev_idx = nullptr;
     hipStream_t stream_win = nullptr;     // scan / flush of the windows, beside the chain on stream_ekf
-    hipEvent_t ev_win[16] = {};
+    hipEvent_t ev_win[64] = {};
+    unsigned win_count = 0;               // windows enqueued so far (parity = which hand-over image a window uses)
     unsigned ev_win_next = 0;
     int ev_obs_next = 0;
     bool ev_idx_set = false;
@@ -126,6 +129,7 @@ struct aslam_ctx {
     std::vector<HostLast> m_last;         // host mirror of last_observed_marker_ (NaN z = unset)
     bool mirror_dirty = true;             // the device planned frames the host could not follow: read the tables back before planning
     int ekf_lo = 0, ekf_hi = 0;           // union of the slot ranges of EKF work enqueued since the last wait on ev_ekf
+    double last_timing[6] = {0, 0, 0, 0, 0, 0};   // aslam_add_image, host clock, microseconds: upload, detection enqueue, EKF enqueue, wait, read-back / checks, total
     long long plan_stats[4] = {0, 0, 0, 0};   // frames inside windows, frames on the per-frame chain, windows, frames left to the device's own plan
 
     // map gather over RCCL without torch (aslam_comm_*): librccl is dlopen'ed on first use
@@ -324,8 +328,13 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_ekf, 0));   // EKF work in flight still reads observations of these slots
         c->ekf_count = 0;
     }
-    for (int f0 = first; f0 < first + count; f0 += max_frames_per_call()) {
-        const int nf = std::min(max_frames_per_call(), first + count - f0);
+    // frames per launch of the detection kernels: everything of the call at once (the work queues balance it) unless
+    // ASLAM_DETECT_CHUNK asks for smaller sub-batches (an experiment knob: mask planes of fewer frames stay cache-resident
+    // between k_threshold and k_trace, at the price of one longest-walk tail per sub-batch)
+    static const int chunk_env = [] { const char* e = std::getenv("ASLAM_DETECT_CHUNK"); return e ? std::max(1, std::atoi(e)) : 0; }();
+    const int chunk = chunk_env > 0 ? std::min(chunk_env, max_frames_per_call()) : max_frames_per_call();
+    for (int f0 = first; f0 < first + count; f0 += chunk) {
+        const int nf = std::min(chunk, first + count - f0);
         HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, kCounterHeads * sizeof(unsigned), st));   // queue heads and work count; the overflow mask is sticky
         HIP_TRY(c, hipMemsetAsync(c->d_nstarts + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_ncontours + f0, 0, sizeof(unsigned) * nf, st));
@@ -510,6 +519,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     c->sp.useful_distance_threshold = init->useful_distance_threshold;
 
     c->win_enabled = std::getenv("ASLAM_NO_WINDOWS") == nullptr;
+    c->win_no_early = std::getenv("ASLAM_WIN_NO_EARLY") != nullptr;
     if (const char* e = std::getenv("ASLAM_WIN_PIECE")) c->win_piece = std::min(kWinChainFrames, std::max(1, std::atoi(e)));
     const int B = c->max_batch;
     const size_t px = (size_t)init->max_rows * init->max_cols;
@@ -581,7 +591,7 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && hipEventCreateWithFlags(&c->ev_obs[1], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_idx, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreateWithPriority(&c->stream_win, hipStreamNonBlocking, prio_hi) == hipSuccess;
-    for (int i = 0; i < 16; i++) ok = ok && hipEventCreateWithFlags(&c->ev_win[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 64; i++) ok = ok && hipEventCreateWithFlags(&c->ev_win[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_obs), (size_t)B * kMarkerMax * sizeof(ObsRaw), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_nm), (size_t)B * sizeof(unsigned), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&c->h_win_frames), (size_t)B * sizeof(WinFrame), hipHostMallocDefault) == hipSuccess;
@@ -617,7 +627,7 @@ void aslam_destroy(aslam_ctx* c) {
     if (c->h_win_frames) hipHostFree(c->h_win_frames);
     for (int h = 0; h < 2; h++) if (c->ev_obs[h]) hipEventDestroy(c->ev_obs[h]);
     if (c->ev_idx) hipEventDestroy(c->ev_idx);
-    for (int i = 0; i < 16; i++) if (c->ev_win[i]) hipEventDestroy(c->ev_win[i]);
+    for (int i = 0; i < 64; i++) if (c->ev_win[i]) hipEventDestroy(c->ev_win[i]);
     if (c->stream_win) { hipStreamSynchronize(c->stream_win); hipStreamDestroy(c->stream_win); }
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->stream_part) hipStreamDestroy(c->stream_part);
@@ -850,55 +860,99 @@ int finalize_pending(aslam_ctx* c) {
         if (o.K == 0) c->plan_stats[1]++;
         else { c->plan_stats[0] += o.K; c->plan_stats[2]++; }
     }
-    for (const Op& o : ops) {
+    // Streams: sa = the EKF stream (chain pieces, per-frame chains), sb = replay (scan + Psi per piece), the window's gather and its
+    // flush.  A window that is followed by another window does not wait for its own flush: the next window's P and mu_S are
+    // derived from this window's small results (launch_ekf_win_next, on sa) while the pass over Sigma runs on sb; only the next
+    // window's LAST piece (which writes mu back) and whatever is not a window wait for the flush.
+    hipStream_t sa = c->stream_ekf, sb = c->stream_win;
+    auto new_event = [&]() { return c->ev_win[c->ev_win_next++ & 63]; };
+    struct { bool active = false; WinDesc wd{}; hipEvent_t ev_psi = nullptr; } pf;      // the previous window's flush, not yet enqueued
+    auto flush_now = [&](const WinDesc& fwd) -> int {                                    // classic order: flush, then the EKF stream goes on
+        prof_begin(c, P_EKF_WIN_FLUSH, sb);
+        launch_ekf_win_flush(sb, c->ekf, fwd);
+        prof_end(c);
+        hipEvent_t ev = new_event();
+        HIP_TRY(c, hipEventRecord(ev, sb));
+        HIP_TRY(c, hipStreamWaitEvent(sa, ev, 0));                   // whatever follows on the EKF stream sees the flushed Sigma
+        return ASLAM_OK;
+    };
+    for (size_t oi = 0; oi < ops.size(); oi++) {
+        const Op& o = ops[oi];
         if (o.K == 0) {
+            if (pf.active) { int r = flush_now(pf.wd); if (r) return r; pf.active = false; }
             const double* e = &c->enc_host[(size_t)3 * o.frame];
             int r = run_ekf_frame(c, o.frame, e[0], e[1], e[2], o.predict);
             if (r) return r;
-        } else {
-            // One window = K frames on the set S.  Its chain is cut into pieces of a few frames on the EKF stream; the replay of
-            // each piece's log (scan + Psi) and the window's single pass over Sigma (flush) go to a second stream, so that only
-            // the last piece's replay and the flush are not hidden behind the chain.
-            hipStream_t sa = c->stream_ekf, sb = c->stream_win;
-            WinDesc wd{};
-            wd.nS = (int)o.S.size();
-            wd.T = ekf_win_tiles(wd.nS);
-            for (int a = 0; a < wd.nS; a++) wd.li[a] = (short)(3 + 3 * o.S[a]);
-            // The chain of the NEXT window waits for this window's last replay and the flush: the last piece is kept short
-            // (kWinLastPiece frames), so that the replay in front of the flush has little left to do.
-            int piece = 0, log0 = 0;
-            for (int k0 = 0, kn = 0; k0 < o.K; k0 += kn, piece++) {
-                const int left = o.K - k0;
-                kn = std::min(c->win_piece, left);
-                if (kn == left && kn > kWinLastPiece) kn -= kWinLastPiece;
-                WinDesc sub = wd;
-                sub.first_slot = o.frame + k0;
-                sub.K = kn;
-                sub.piece = piece;
-                sub.log0 = log0;
-                sub.last = k0 + kn == o.K ? 1 : 0;
-                int nsteps = 0;
-                for (int k = 0; k < kn; k++) nsteps += 1 + c->h_win_frames[sub.first_slot + k].m;
-                prof_begin(c, P_EKF_WIN_CHAIN, sa);
-                launch_ekf_win_chain(sa, c->ekf, c->sp, sub, c->d_obs, c->d_enc);
-                prof_end(c);
-                hipEvent_t ev = c->ev_win[c->ev_win_next++ & 15];
-                HIP_TRY(c, hipEventRecord(ev, sa));
-                HIP_TRY(c, hipStreamWaitEvent(sb, ev, 0));
-                prof_begin(c, P_EKF_WIN_SCAN, sb);
-                launch_ekf_win_scan(sb, c->ekf, sub, nsteps);
-                prof_end(c);
-                log0 += nsteps;
-            }
-            prof_begin(c, P_EKF_WIN_FLUSH, sb);
-            launch_ekf_win_flush(sb, c->ekf, wd);
+            continue;
+        }
+        // One window = K frames on the set S.  Its chain is cut into pieces of a few frames on sa; the replay of each piece's
+        // log goes to sb, so that only the last piece's replay is not hidden behind the chain.
+        WinDesc wd{};
+        wd.nS = (int)o.S.size();
+        wd.T = ekf_win_tiles(wd.nS);
+        wd.wpar = (int)(c->win_count++ & 1u);
+        for (int a = 0; a < wd.nS; a++) wd.li[a] = (short)(3 + 3 * o.S[a]);
+        hipEvent_t ev_prev_flush = nullptr;
+        if (pf.active) {
+            HIP_TRY(c, hipStreamWaitEvent(sa, pf.ev_psi, 0));        // the previous window's Lambda, Psi, psi are complete
+            prof_begin(c, P_EKF_WIN_NEXT, sa);
+            launch_ekf_win_next(sa, c->ekf, pf.wd, wd);
             prof_end(c);
-            hipEvent_t ev = c->ev_win[c->ev_win_next++ & 15];
-            HIP_TRY(c, hipEventRecord(ev, sb));
-            HIP_TRY(c, hipStreamWaitEvent(sa, ev, 0));               // whatever follows on the EKF stream sees the flushed Sigma
-            HIP_TRY(c, hipGetLastError());
+            hipEvent_t ev_next = new_event();
+            HIP_TRY(c, hipEventRecord(ev_next, sa));
+            HIP_TRY(c, hipStreamWaitEvent(sb, ev_next, 0));          // the flush rewrites what launch_ekf_win_next reads (Sigma, mu, Y_0)
+            prof_begin(c, P_EKF_WIN_FLUSH, sb);
+            launch_ekf_win_flush(sb, c->ekf, pf.wd);
+            prof_end(c);
+            ev_prev_flush = new_event();
+            HIP_TRY(c, hipEventRecord(ev_prev_flush, sb));
+            pf.active = false;
+            wd.from_image = 1;
+        } else {
+            hipEvent_t ev = new_event();
+            HIP_TRY(c, hipEventRecord(ev, sa));
+            HIP_TRY(c, hipStreamWaitEvent(sb, ev, 0));               // Sigma as the EKF stream leaves it
+        }
+        launch_ekf_win_gather(sb, c->ekf, wd);                       // Y_0 of this window (behind the previous window's flush: same stream)
+        // The chain of whatever follows waits for this window's last replay: the last piece is kept short (kWinLastPiece frames).
+        int piece = 0, log0 = 0;
+        for (int k0 = 0, kn = 0; k0 < o.K; k0 += kn, piece++) {
+            const int left = o.K - k0;
+            kn = std::min(c->win_piece, left);
+            if (kn == left && kn > kWinLastPiece) kn -= kWinLastPiece;
+            WinDesc sub = wd;
+            sub.first_slot = o.frame + k0;
+            sub.K = kn;
+            sub.piece = piece;
+            sub.log0 = log0;
+            sub.last = k0 + kn == o.K ? 1 : 0;
+            int nsteps = 0;
+            for (int k = 0; k < kn; k++) nsteps += 1 + c->h_win_frames[sub.first_slot + k].m;
+            if (sub.last && ev_prev_flush) HIP_TRY(c, hipStreamWaitEvent(sa, ev_prev_flush, 0));   // mu_S goes back into the state: after the previous flush's mu_R pass
+            prof_begin(c, P_EKF_WIN_CHAIN, sa);
+            launch_ekf_win_chain(sa, c->ekf, c->sp, sub, c->d_obs, c->d_enc);
+            prof_end(c);
+            hipEvent_t ev = new_event();
+            HIP_TRY(c, hipEventRecord(ev, sa));
+            HIP_TRY(c, hipStreamWaitEvent(sb, ev, 0));
+            prof_begin(c, P_EKF_WIN_SCAN, sb);
+            launch_ekf_win_scan(sb, c->ekf, sub, nsteps);
+            prof_end(c);
+            log0 += nsteps;
+        }
+        HIP_TRY(c, hipGetLastError());
+        const bool next_is_window = oi + 1 < ops.size() && ops[oi + 1].K > 0 && !c->win_no_early;
+        if (next_is_window) {
+            pf.active = true; pf.wd = wd;
+            pf.ev_psi = new_event();
+            HIP_TRY(c, hipEventRecord(pf.ev_psi, sb));
+        } else {
+            int r = flush_now(wd);
+            if (r) return r;
         }
     }
+    if (pf.active) { int r = flush_now(pf.wd); if (r) return r; }
+    HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_ekf, c->stream_ekf));
     note_ekf_range(c, p.first, p.count);
     return ASLAM_OK;
@@ -1160,15 +1214,33 @@ int aslam_add_image(aslam_ctx* c, const uint8_t* px, int rows, int cols, int cha
     int r = finalize_pending(c);
     if (r) return r;
     if (!c->is_init) return ASLAM_OK;        // aruco_slam.cpp:84-85: nothing happens before the first encoder message
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
     c->mirror_dirty = true;                  // planned on the device: the host's copy of the tables is stale afterwards
     r = aslam_stage_frames(c, 0, px, 1, rows, cols, channels, step, 0);
     if (r) return r;
+    const auto t1 = clk::now();
     r = run_detect(c, 0, 1);
     if (r) return r;
+    const auto t2 = clk::now();
     HIP_TRY(c, hipStreamWaitEvent(c->stream_ekf, c->ev_detect, 0));
     r = run_ekf_frame(c, 0, 0, 0, 0, false);
     if (r) return r;
-    return sync_and_check(c);
+    const auto t3 = clk::now();
+    r = sync_streams(c);
+    const auto t4 = clk::now();
+    if (!r) r = sync_and_check(c);
+    const auto t5 = clk::now();
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    c->last_timing[0] = us(t0, t1); c->last_timing[1] = us(t1, t2); c->last_timing[2] = us(t2, t3); c->last_timing[3] = us(t3, t4);
+    c->last_timing[4] = us(t4, t5); c->last_timing[5] = us(t0, t5);
+    return r;
+}
+
+int aslam_get_last_timing(aslam_ctx* c, double out[6]) {
+    if (!c || !out) return ASLAM_E_INVALID;
+    for (int i = 0; i < 6; i++) out[i] = c->last_timing[i];
+    return ASLAM_OK;
 }
 
 int aslam_get_state(aslam_ctx* c, int* N, double* mu, double* sigma) {

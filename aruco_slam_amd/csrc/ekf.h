@@ -49,7 +49,9 @@ struct WinDesc {                       // one chain piece / one window (kernel a
     int first_slot, K;                 // slots first_slot .. first_slot + K - 1
     int nS, T;                         // landmarks in S; MFMA tiles per side: SP = 16 T >= s = 3 + 3 nS  (T = 4, 8 or 12)
     int piece, log0;                   // index of the piece within its window; steps logged by the earlier pieces
-    int last, pad;                     // 1 = the window's last piece: the last frame's pop list / last-observation list are left behind
+    int last;                          // 1 = the window's last piece: mu_S goes back to the state, the last frame's pop list / last-observation list are left behind
+    int wpar;                          // parity of the window within its batch: which of the two P / mu hand-over images it uses
+    int from_image, pad;               // first piece of a window whose P and mu_S were prepared in the image (k_ekf_win_next_*) instead of read from Sigma / mu
     short li[kWinSMax + 1];            // state offset 3 + 3 index of every landmark of S, ascending
 };
 
@@ -72,7 +74,9 @@ struct EkfState {
     MapRecord* d_maprec;
     double* d_win_log;                 // per window step: operand rows -K^T (3 x SP) + header (ekf_window.hip)
     double* d_win_tlog;                // per window step: t = H Lambda and u = S^-1 t (4 x SP each, 4th row zero)
-    double* d_win_small;               // P_K, Lambda, Psi images (SP x SP) and psi
+    double* d_win_small;               // two P images and mu_S images (hand-over between the pieces of a window), Lambda, Psi images (SP x SP) and psi
+    double* d_win_next;                // early start of the next window: Y_0 columns S' (Vg), Psi Vg, Lambda Vg, Sigma[S',S'] (each SPm x SPm)
+    int* d_win_next_idx;               // ... position in the previous S of every entry of S' (or -1), and nS' (at [SPm])
     int* d_win_sidx;                   // per state index: position in S or -1
     WinFrame* d_win_frames;            // per staged slot: the host's plan of the frame
     int win_sp_max, win_steps_max;     // capacity: largest SP and most steps (frames + corrections) per window
@@ -98,6 +102,9 @@ void launch_ekf_export_map(hipStream_t st, const EkfState& E);
 int ekf_win_tiles(int nS);             // T for a set of nS landmarks (4, 8 or 12)
 // obs / enc: the context's per-slot arrays
 void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc);
+void launch_ekf_win_gather(hipStream_t st, const EkfState& E, const WinDesc& wd);               // Y_0 = rows S of Sigma, position table
+// P and mu_S of the NEXT window (set nx) from the previous window's (pv) P_K, Lambda, Psi, psi, Y_0 and the not yet flushed Sigma / mu
+void launch_ekf_win_next(hipStream_t st, const EkfState& E, const WinDesc& pv, const WinDesc& nx);
 void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd, int nsteps);      // + Psi accumulation of the piece
 void launch_ekf_win_flush(hipStream_t st, const EkfState& E, const WinDesc& wd);                 // thin products, Sigma pass, rows / columns of S
 

@@ -1333,7 +1333,9 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots, int max_upda
     E.win_steps_max = kWinFrames * (1 + std::min(max_updates_per_frame, kWinCorrMax));
     A(dalloc(&E.d_win_log, (size_t)E.win_steps_max * (3 * E.win_sp_max + kWinHdr) + 512));
     A(dalloc(&E.d_win_tlog, (size_t)E.win_steps_max * 8 * E.win_sp_max));
-    A(dalloc(&E.d_win_small, (size_t)3 * E.win_sp_max * E.win_sp_max + E.win_sp_max));
+    A(dalloc(&E.d_win_small, (size_t)4 * E.win_sp_max * E.win_sp_max + 3 * E.win_sp_max));
+    A(dalloc(&E.d_win_next, (size_t)4 * E.win_sp_max * E.win_sp_max));
+    A(dalloc(&E.d_win_next_idx, (size_t)E.win_sp_max + 4));
     A(dalloc(&E.d_win_sidx, ld));
     A(dalloc(&E.d_win_frames, (size_t)max_slots));
     A(dalloc(&E.d_slot_stat, (size_t)4 * max_slots));
@@ -1355,7 +1357,7 @@ void ekf_free(EkfState& E) {
     hipFree(E.d_mu); hipFree(E.d_sigma); hipFree(E.d_L); hipFree(E.d_id2idx); hipFree(E.d_idx2id); hipFree(E.d_last); hipFree(E.d_lastNext);
     hipFree(E.d_nlast); hipFree(E.d_pop); hipFree(E.d_npop); hipFree(E.d_upd); hipFree(E.d_m); hipFree(E.d_V); hipFree(E.d_Wt);
     hipFree(E.d_T); hipFree(E.d_Sv); hipFree(E.d_Sw); hipFree(E.d_alpha); hipFree(E.d_gamma); hipFree(E.d_G); hipFree(E.d_g);
-    hipFree(E.d_maprec); hipFree(E.d_slot_stat); hipFree(E.d_win_log); hipFree(E.d_win_tlog); hipFree(E.d_win_small); hipFree(E.d_win_sidx); hipFree(E.d_win_frames);
+    hipFree(E.d_maprec); hipFree(E.d_slot_stat); hipFree(E.d_win_log); hipFree(E.d_win_tlog); hipFree(E.d_win_small); hipFree(E.d_win_next); hipFree(E.d_win_next_idx); hipFree(E.d_win_sidx); hipFree(E.d_win_frames);
     E = EkfState{};
 }
 

@@ -53,10 +53,11 @@ __host__ __device__ inline int win_tlog_stride(int T) { return 8 * 16 * T; }
 // header of a logged step (doubles after the three operand rows)
 enum { WH_TYPE = 0, WH_POS = 1, WH_SI = 2, WH_ZE = 11, WH_C = 14, WH_S = 15, WH_G02 = 16, WH_G12 = 17, WH_A = 18, WH_B = 19 };
 // d_win_small: images of the window, each SPm x SPm at most (SPm = E.win_sp_max), stored with the window's own row stride SP
-__host__ __device__ inline size_t wsm_P(int) { return 0; }
-__host__ __device__ inline size_t wsm_LAM(int SPm) { return (size_t)SPm * SPm; }
-__host__ __device__ inline size_t wsm_PSI(int SPm) { return (size_t)2 * SPm * SPm; }
-__host__ __device__ inline size_t wsm_psi(int SPm) { return (size_t)3 * SPm * SPm; }
+__host__ __device__ inline size_t wsm_P(int SPm, int par) { return (size_t)par * SPm * SPm; }             // P image of window parity par
+__host__ __device__ inline size_t wsm_LAM(int SPm) { return (size_t)2 * SPm * SPm; }
+__host__ __device__ inline size_t wsm_PSI(int SPm) { return (size_t)3 * SPm * SPm; }
+__host__ __device__ inline size_t wsm_psi(int SPm) { return (size_t)4 * SPm * SPm; }
+__host__ __device__ inline size_t wsm_MU(int SPm, int par) { return (size_t)4 * SPm * SPm + (size_t)(1 + par) * SPm; }   // mu_S image
 
 int ekf_win_tiles(int nS) { return nS <= 20 ? 4 : nS <= 41 ? 8 : 12; }
 
@@ -112,12 +113,13 @@ __device__ __forceinline__ void win_publish(const v4d (&acc)[RW][T], int p, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// T tiles per side, RW tile rows per worker wave: T / RW worker waves + 1 prepare wave.
+// T tiles per side, RW tile rows per worker wave: ceil(T / RW) worker waves + 1 prepare wave.  With T = 4 (2 x 2 rows) and T = 8
+// (3 + 3 + 2 rows) the prepare wave - the kernel's critical path - has a SIMD to itself (measured: -11 % per step).
 template <int T, int RW>
-__global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E, SlamParams sp, WinDesc wd, const ObsRaw* __restrict__ obs,
+__global__ __launch_bounds__(((T + RW - 1) / RW + 1) * 64) void k_ekf_win_chain(EkfState E, SlamParams sp, WinDesc wd, const ObsRaw* __restrict__ obs,
                                                                     const double* __restrict__ enc) {
     constexpr int SP = 16 * T, SPP = SP + 16, NC = SP / 64;       // SPP: operand rows lk and lk + 1 fall on opposite halves of the bank row
-    constexpr int NWK = T / RW, NT = (NWK + 1) * 64;
+    constexpr int NWK = (T + RW - 1) / RW, NT = (NWK + 1) * 64;
     constexpr int NSMAX = kWinPieceMax * 64;
     __shared__ __align__(16) double sA[2][4][SPP];                 // a step's A operand rows  Aop[k][row]   (P += Aop^T Bop)
     __shared__ __align__(16) double sB[2][4][SPP];                 // ... and B operand rows   Bop[k][column]
@@ -131,23 +133,6 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
     const int ld = E.ld;
     const WinFrame* __restrict__ frames = E.d_win_frames;
 
-    if (blockIdx.x > 0) {
-        // ---- further workgroups of a window's first piece: Y_0 (row p = row S_p of Sigma = its column S_p) -> d_Wt, position table ----
-        const int N = 3 + 3 * (*E.d_L);
-        for (int t = (blockIdx.x - 1) * NT + tid; t < N; t += (gridDim.x - 1) * NT) {
-            int pos = -1;
-            if (t < 3) pos = t;
-            else {
-                const int base = (t - 3) / 3 * 3 + 3;
-                for (int a = 0; a < nS; a++) if (wd.li[a] == base) pos = 3 + 3 * a + (t - base);
-            }
-            E.d_win_sidx[t] = pos;
-            for (int p = 0; p < SP; p++) E.d_Wt[(size_t)p * ld + t] = p < s ? E.d_sigma[(size_t)win_state_index(wd, p) * ld + t] : 0.0;
-        }
-        return;
-    }
-
-    // ---- workgroup 0 ----
     const int wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
     for (int e = tid; e < SP; e += NT) sS[e] = e < s ? win_state_index(wd, e) : 0;
@@ -174,7 +159,8 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
     if (wave < NWK) {
         // =================================== worker waves: P in the accumulators ===================================
         v4d acc[RW][T];
-        const double* Pimg = E.d_win_small + wsm_P(E.win_sp_max);
+        const double* Pimg = E.d_win_small + wsm_P(E.win_sp_max, wd.wpar);
+        const bool from_img = wd.piece != 0 || wd.from_image != 0;
 #pragma unroll
         for (int rr = 0; rr < RW; rr++)
 #pragma unroll
@@ -183,8 +169,10 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
                 for (int reg = 0; reg < 4; reg++) {
                     const int r = 16 * (wave * RW + rr) + lk + 4 * reg, c = 16 * t + li;
                     double v = 0.0;
-                    if (wd.piece) v = Pimg[(size_t)r * SP + c];                    // the run goes on: P as the previous piece left it
-                    else if (r < s && c < s) v = E.d_sigma[(size_t)sS[c] * ld + sS[r]];
+                    if (r < SP) {                                                  // (the last worker may own fewer than RW tile rows)
+                        if (from_img) v = Pimg[(size_t)r * SP + c];                // the window goes on (or was prepared ahead): P from the image
+                        else if (r < s && c < s) v = E.d_sigma[(size_t)sS[c] * ld + sS[r]];
+                    }
                     acc[rr][t][reg] = v;
                 }
         // rows of step 0 (pose rows only: a predict) and of step 1, as they stand before any step
@@ -210,6 +198,7 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
                 for (int t = 0; t < T; t++) b[t] = sB[cb][lk][16 * t + li];
 #pragma unroll
                 for (int rr = 0; rr < RW; rr++) {
+                    if (T % RW != 0 && wave * RW + rr >= T) break;
                     const double a = sA[cb][lk][16 * (wave * RW + rr) + li];
 #pragma unroll
                     for (int t = 0; t < T; t++) acc[rr][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[t], acc[rr][t], 0, 0, 0);
@@ -234,13 +223,14 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
         if (lane == 0 && wd.piece == 1) printf("worker %d T %d steps %d: barrier-wait %lld work %lld cycles per step\n", wave, T, NS, stamp_acc[0] / (NS + 1), stamp_acc[1] / (NS + 1));
 #endif
         // P_K for the next piece / the flush
-        double* Pout = E.d_win_small + wsm_P(E.win_sp_max);
+        double* Pout = E.d_win_small + wsm_P(E.win_sp_max, wd.wpar);
 #pragma unroll
         for (int rr = 0; rr < RW; rr++)
 #pragma unroll
             for (int t = 0; t < T; t++)
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) Pout[(size_t)(16 * (wave * RW + rr) + lk + 4 * reg) * SP + 16 * t + li] = acc[rr][t][reg];
+                for (int reg = 0; reg < 4; reg++)
+                    if (T % RW == 0 || wave * RW + rr < T) Pout[(size_t)(16 * (wave * RW + rr) + lk + 4 * reg) * SP + 16 * t + li] = acc[rr][t][reg];
         return;
     }
 
@@ -248,13 +238,18 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
     // What a step needs from another column (the previous step's A operand at the six row indices, c at the six special columns)
     // is wave-uniform and is read back from LDS as a broadcast - the operands live there anyway (measured: cheaper than v_readlane
     // plus chunk selection).
+#ifndef ASLAM_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);                                  // the critical path of the kernel: wins the issue slot over the worker wave it shares a SIMD with
+#endif
     const double kl = sp.kl, kr = sp.kr, inv2b = 1.0 / (2 * sp.b), invb = 1 / sp.b, Qk = sp.Q_k;
     double* const logbase = E.d_win_log + (size_t)wd.log0 * win_log_stride(T);
+    double* const muimg = E.d_win_small + wsm_MU(E.win_sp_max, wd.wpar);
     double mu[NC], pB[4][NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const int col = lane + 64 * c;
-        mu[c] = col < s ? E.d_mu[sS[col]] : 0.0;
+        // mu_S travels between the pieces of a window in its image; only the window's last piece puts it back into the state
+        mu[c] = col >= s ? 0.0 : (wd.piece != 0 || wd.from_image != 0) ? muimg[col] : E.d_mu[sS[col]];
 #pragma unroll
         for (int k = 0; k < 4; k++) pB[k][c] = 0.0;
     }
@@ -472,9 +467,12 @@ __global__ __launch_bounds__((T / RW + 1) * 64) void k_ekf_win_chain(EkfState E,
                stamp_acc[5] / (nc ? nc : 1), stamp_acc[6] / NS);
     }
 #endif
-    // ---- mu_S in place ----
+    // ---- mu_S for the next piece; back into the state at the window's end ----
 #pragma unroll
-    for (int c = 0; c < NC; c++) { const int col = lane + 64 * c; if (col < s) E.d_mu[sS[col]] = mu[c]; }
+    for (int c = 0; c < NC; c++) {
+        const int col = lane + 64 * c;
+        if (col < s) { muimg[col] = mu[c]; if (wd.last) E.d_mu[sS[col]] = mu[c]; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -620,54 +618,56 @@ __global__ __launch_bounds__(256) void k_ekf_win_psi(EkfState E, WinDesc wd, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Per 64 columns of Sigma: U = Psi Y_0blk -> d_T, Y_K = Lambda Y_0blk -> d_V (both SP x 64, matrix cores), mu_R += Y_0^T psi.
-// Y_0blk passes through LDS in chunks of 64 rows (B operand); Psi / Lambda come straight from L2 in MFMA layout (A[i][k] in lane
-// 16 k + i).  Wave w owns columns 16 w .. 16 w + 15 of the block and all T tile rows of both products.
+// U = Psi Y_0 -> d_T and Y_K = Lambda Y_0 -> d_V (both SP x N) as ONE product [Psi; Lambda] (2 SP x SP) . Y_0 (SP x N) on the matrix
+// cores: workgroup (x, y) = 64 columns of Sigma x 64 rows of the stacked matrix, depth in chunks of 64 staged through LDS (both
+// operands, coalesced), wave w = 16 of the columns x all 64 rows.  Workgroups with y = 0 also add Y_0^T psi to their 64 entries
+// of mu_R.
 template <int T>
 __global__ __launch_bounds__(256) void k_ekf_win_thin(EkfState E, WinDesc wd) {
     constexpr int SP = 16 * T, YS = 66;
-    __shared__ double sY[64 * YS];
+    __shared__ double sY[64 * YS];                                  // Y_0 chunk: [depth][column]
+    __shared__ double sM[64 * YS];                                  // Psi / Lambda chunk: [row][depth]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
     const int ld = E.ld;
     const int N = 3 + 3 * (*E.d_L);
     const int c0 = blockIdx.x * 64;
     if (c0 >= N) return;
+    const int r0 = blockIdx.y * 64;                                 // row of the stacked matrix
+    const bool lam = r0 >= SP;
     const int s = 3 + 3 * wd.nS;
-    const double* Psi = E.d_win_small + wsm_PSI(E.win_sp_max);
-    const double* Lam = E.d_win_small + wsm_LAM(E.win_sp_max);
+    const double* M = E.d_win_small + (lam ? wsm_LAM(E.win_sp_max) : wsm_PSI(E.win_sp_max)) + (size_t)(lam ? r0 - SP : r0) * SP;
     const double* psi = E.d_win_small + wsm_psi(E.win_sp_max);
-    v4d aU[T], aY[T];
+    double* out = lam ? E.d_V : E.d_T;
+    const int orow = lam ? r0 - SP : r0;
+    v4d acc[4];
 #pragma unroll
-    for (int tr = 0; tr < T; tr++) { aU[tr] = v4d{0.0, 0.0, 0.0, 0.0}; aY[tr] = v4d{0.0, 0.0, 0.0, 0.0}; }
+    for (int q = 0; q < 4; q++) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
     double macc = 0.0;
     for (int ch = 0; ch < SP / 64; ch++) {
         if (ch) __syncthreads();
         for (int e = tid; e < 64 * 64; e += 256) {
             const int p = e >> 6, x = e & 63;
             sY[p * YS + x] = c0 + x < N ? E.d_Wt[(size_t)(64 * ch + p) * ld + c0 + x] : 0.0;
+            sM[p * YS + x] = M[(size_t)p * SP + 64 * ch + x];
         }
         __syncthreads();
         for (int p0 = 0; p0 < 64; p0 += 4) {
             const double bv = sY[(p0 + lk) * YS + 16 * wave + li];
 #pragma unroll
-            for (int tr = 0; tr < T; tr++) {
-                const size_t off = (size_t)(16 * tr + li) * SP + 64 * ch + p0 + lk;
-                aU[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(Psi[off], bv, aU[tr], 0, 0, 0);
-                aY[tr] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lam[off], bv, aY[tr], 0, 0, 0);
-            }
+            for (int q = 0; q < 4; q++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(sM[(16 * q + li) * YS + p0 + lk], bv, acc[q], 0, 0, 0);
         }
-        if (tid < 64)
+        if (blockIdx.y == 0 && tid < 64)
             for (int p = 0; p < 64 && 64 * ch + p < s; p++) macc += sY[p * YS + tid] * psi[64 * ch + p];
     }
 #pragma unroll
-    for (int tr = 0; tr < T; tr++)
+    for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-            const int p = 16 * tr + lk + 4 * reg, c = c0 + 16 * wave + li;
-            if (c < N) { E.d_T[(size_t)p * ld + c] = aU[tr][reg]; E.d_V[(size_t)p * ld + c] = aY[tr][reg]; }
+            const int p = orow + 16 * q + lk + 4 * reg, c = c0 + 16 * wave + li;
+            if (c < N) out[(size_t)p * ld + c] = acc[q][reg];
         }
-    if (tid < 64 && c0 + tid < N && E.d_win_sidx[c0 + tid] < 0) E.d_mu[c0 + tid] += macc;      // mu_R += Y_0^T psi
+    if (blockIdx.y == 0 && tid < 64 && c0 + tid < N && E.d_win_sidx[c0 + tid] < 0) E.d_mu[c0 + tid] += macc;      // mu_R += Y_0^T psi
 }
 
 // Rows and columns S of Sigma after the Z pass: row S_p <- Y_K[p][:], column S_p <- the same (symmetry), (S_p, S_q) <- P_K[p][q].
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_fix(EkfState E, WinDesc wd, int
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= N) return;
     const int tp = E.d_win_sidx[t];
-    const double* Pimg = E.d_win_small + wsm_P(E.win_sp_max);
+    const double* Pimg = E.d_win_small + wsm_P(E.win_sp_max, wd.wpar);
     for (int p = blockIdx.y; p < s; p += gridDim.y) {
         const int Sp = win_state_index(wd, p);
         const double v = tp >= 0 ? Pimg[(size_t)p * SP + tp] : E.d_V[(size_t)p * ld + t];
@@ -687,13 +687,99 @@ __global__ __launch_bounds__(256) void k_ekf_win_fix(EkfState E, WinDesc wd, int
     }
 }
 
+// Y_0 (row p = row S_p of Sigma = its column S_p) -> d_Wt (rows s .. SP - 1 zero), position table of S.
+__global__ __launch_bounds__(256) void k_ekf_win_gather(EkfState E, WinDesc wd) {
+    const int ld = E.ld, nS = wd.nS, s = 3 + 3 * nS, SP = 16 * wd.T;
+    const int N = 3 + 3 * (*E.d_L);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= N) return;
+    int pos = -1;
+    if (t < 3) pos = t;
+    else {
+        const int base = (t - 3) / 3 * 3 + 3;
+        for (int a = 0; a < nS; a++) if (wd.li[a] == base) pos = 3 + 3 * a + (t - base);
+    }
+    E.d_win_sidx[t] = pos;
+    for (int p = 0; p < SP; p++) E.d_Wt[(size_t)p * ld + t] = p < s ? E.d_sigma[(size_t)win_state_index(wd, p) * ld + t] : 0.0;
+}
+
+// ---- early start of the next window -----------------------------------------------------------------------------------
+// The chain of the window that follows needs only P' = Sigma[S', S'] and mu_S' as they will stand AFTER the previous window's
+// flush; both follow from the previous window's small results without the pass over Sigma:
+//     (a, b in S)      P_K                 (a in S, b not)   (Lambda Y_0)[a][b]            (neither)   Sigma_old[a][b] - (Y_0^T Psi Y_0)[a][b]
+//     mu: in S as the chain left it, otherwise mu_old + Y_0^T psi.
+// k_ekf_win_next_gather collects Y_0's columns S' (Vg, zero where the entry is in S), Sigma_old[S', S'] and mu_old[S'] into
+// small dense buffers with the index tables a miniature EkfState view needs; k_ekf_win_thin and k_ekf_update_mfma then run on that
+// view (N := s'), and k_ekf_win_next_fix assembles the image the chain loads.  The flush of the previous window runs meanwhile.
+__global__ __launch_bounds__(256) void k_ekf_win_next_gather(EkfState E, WinDesc pv, WinDesc nx) {
+    const int ld = E.ld, SPm = E.win_sp_max;
+    const int s2 = 3 + 3 * nx.nS, SPp = 16 * pv.T;
+    double* Vg = E.d_win_next;                                      // [p][a'] row stride SPm
+    double* Ptmp = E.d_win_next + (size_t)3 * SPm * SPm;            // column-major, ld SPm
+    double* mu2 = E.d_win_small + wsm_MU(SPm, nx.wpar);
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= s2) return;
+    const int ia = win_state_index(nx, a);
+    const int pa = E.d_win_sidx[ia];
+    if (blockIdx.y == 0) {
+        E.d_win_next_idx[a] = pa;
+        if (a == 0) E.d_win_next_idx[SPm] = nx.nS;
+        mu2[a] = E.d_mu[ia];
+        for (int p = 0; p < SPp; p++) Vg[(size_t)p * SPm + a] = pa < 0 ? E.d_Wt[(size_t)p * ld + ia] : 0.0;
+    }
+    for (int b = blockIdx.y; b < s2; b += gridDim.y) Ptmp[(size_t)b * SPm + a] = E.d_sigma[(size_t)win_state_index(nx, b) * ld + ia];
+}
+__global__ __launch_bounds__(256) void k_ekf_win_next_fix(EkfState E, WinDesc pv, WinDesc nx) {
+    const int SPm = E.win_sp_max, SPp = 16 * pv.T, SPn = 16 * nx.T;
+    const int s2 = 3 + 3 * nx.nS;
+    const double* Lg = E.d_win_next + (size_t)2 * SPm * SPm;        // (Lambda Vg)[p][a']
+    const double* Ptmp = E.d_win_next + (size_t)3 * SPm * SPm;
+    const double* Pprev = E.d_win_small + wsm_P(SPm, pv.wpar);
+    double* Pout = E.d_win_small + wsm_P(SPm, nx.wpar);
+    const int b = blockIdx.x * 256 + threadIdx.x;                   // column of the image (fastest)
+    if (b >= SPn) return;
+    const int pb = b < s2 ? E.d_win_next_idx[b] : -1;
+    for (int a = blockIdx.y; a < SPn; a += gridDim.y) {
+        double v = 0.0;
+        if (a < s2 && b < s2) {
+            const int pa = E.d_win_next_idx[a];
+            v = pa >= 0 && pb >= 0 ? Pprev[(size_t)pa * SPp + pb] : pa >= 0 ? Lg[(size_t)pa * SPm + b] : pb >= 0 ? Lg[(size_t)pb * SPm + a] : Ptmp[(size_t)b * SPm + a];
+        }
+        Pout[(size_t)a * SPn + b] = v;
+    }
+}
+
 // ---- host side --------------------------------------------------------------------------------------------------------
 void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc) {
-    const int nt = wd.T == 12 ? 448 : 320;
-    const int ngather = wd.piece == 0 ? (E.ld + nt - 1) / nt : 0;
-    if (wd.T == 4) hipLaunchKernelGGL((k_ekf_win_chain<4, 1>), dim3(1 + ngather), dim3(320), 0, st, E, sp, wd, obs, enc);
-    else if (wd.T == 8) hipLaunchKernelGGL((k_ekf_win_chain<8, 2>), dim3(1 + ngather), dim3(320), 0, st, E, sp, wd, obs, enc);
-    else hipLaunchKernelGGL((k_ekf_win_chain<12, 2>), dim3(1 + ngather), dim3(448), 0, st, E, sp, wd, obs, enc);
+    if (wd.T == 4) hipLaunchKernelGGL((k_ekf_win_chain<4, 2>), dim3(1), dim3(192), 0, st, E, sp, wd, obs, enc);
+    else if (wd.T == 8) hipLaunchKernelGGL((k_ekf_win_chain<8, 3>), dim3(1), dim3(256), 0, st, E, sp, wd, obs, enc);
+    else hipLaunchKernelGGL((k_ekf_win_chain<12, 2>), dim3(1), dim3(448), 0, st, E, sp, wd, obs, enc);
+}
+void launch_ekf_win_gather(hipStream_t st, const EkfState& E, const WinDesc& wd) {
+    hipLaunchKernelGGL(k_ekf_win_gather, dim3((E.ld + 255) / 256), dim3(256), 0, st, E, wd);
+}
+static void launch_thin(hipStream_t st, const EkfState& E, const WinDesc& wd, int ncols) {
+    const int SP = 16 * wd.T, nb = (ncols + 63) / 64;
+    if (wd.T == 4) hipLaunchKernelGGL(k_ekf_win_thin<4>, dim3(nb, 2 * SP / 64), dim3(256), 0, st, E, wd);
+    else if (wd.T == 8) hipLaunchKernelGGL(k_ekf_win_thin<8>, dim3(nb, 2 * SP / 64), dim3(256), 0, st, E, wd);
+    else hipLaunchKernelGGL(k_ekf_win_thin<12>, dim3(nb, 2 * SP / 64), dim3(256), 0, st, E, wd);
+}
+void launch_ekf_win_next(hipStream_t st, const EkfState& E, const WinDesc& pv, const WinDesc& nx) {
+    const int SPm = E.win_sp_max, s2 = 3 + 3 * nx.nS, SPn = 16 * nx.T;
+    hipLaunchKernelGGL(k_ekf_win_next_gather, dim3((s2 + 255) / 256, 16), dim3(256), 0, st, E, pv, nx);
+    // the miniature state the previous window's thin products and the Sigma pass run on: N := s', Sigma := Sigma_old[S', S']
+    EkfState E2 = E;
+    E2.ld = SPm;
+    E2.d_sigma = E.d_win_next + (size_t)3 * SPm * SPm;
+    E2.d_Wt = E.d_win_next;                                         // Vg
+    E2.d_T = E.d_win_next + (size_t)1 * SPm * SPm;                  // Psi Vg
+    E2.d_V = E.d_win_next + (size_t)2 * SPm * SPm;                  // Lambda Vg
+    E2.d_mu = E.d_win_small + wsm_MU(SPm, nx.wpar);
+    E2.d_win_sidx = E.d_win_next_idx;
+    E2.d_L = E.d_win_next_idx + SPm;
+    launch_thin(st, E2, pv, s2);
+    launch_ekf_update_mfma(st, E2, 16 * pv.T);
+    hipLaunchKernelGGL(k_ekf_win_next_fix, dim3((SPn + 255) / 256, 16), dim3(256), 0, st, E, pv, nx);
 }
 void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd, int nsteps) {
     if (wd.T == 4) {
@@ -709,10 +795,7 @@ void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd, i
 }
 void launch_ekf_win_flush(hipStream_t st, const EkfState& E, const WinDesc& wd) {
     const int SP = 16 * wd.T;
-    const int nb = (E.ld + 63) / 64;
-    if (wd.T == 4) hipLaunchKernelGGL(k_ekf_win_thin<4>, dim3(nb), dim3(256), 0, st, E, wd);
-    else if (wd.T == 8) hipLaunchKernelGGL(k_ekf_win_thin<8>, dim3(nb), dim3(256), 0, st, E, wd);
-    else hipLaunchKernelGGL(k_ekf_win_thin<12>, dim3(nb), dim3(256), 0, st, E, wd);
+    launch_thin(st, E, wd, E.ld);
     launch_ekf_update_mfma(st, E, SP);                            // Sigma -= Y_0^T U (d_Wt = Y_0, d_T = U), rows / columns S included
     hipLaunchKernelGGL(k_ekf_win_fix, dim3((E.ld + 255) / 256, 16), dim3(256), 0, st, E, wd, SP);
 }

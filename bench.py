@@ -373,18 +373,24 @@ def add_image_latency(np, capi, run, n=120):
     ctx.set_state(mu, sigma, ids)
     ctx.add_encoder(0.0, 0.0, 0.0)
     bgr = [np.ascontiguousarray(np.repeat(host[i][:, :, None], 3, axis=2)) for i in range(n)]
-    lat_img, lat_both = [], []
+    lat_img, lat_both, parts = [], [], []
     t_now = 0.0
     for i in range(n):
         fr = turn if i == 0 else frames[i]
         t_now += fr.dt
+        if i == n - 24:                                  # the last frames run with the per-kernel HIP-event spans on (not part of the percentiles)
+            ctx.profile_enable(True); ctx.profile_reset()
         t0 = time.perf_counter()
         ctx.add_encoder(fr.wl, fr.wr, t_now)
         t1 = time.perf_counter()
         ctx.add_image(bgr[i])
         t2 = time.perf_counter()
-        lat_img.append(t2 - t1)
-        lat_both.append(t2 - t0)
+        if i < n - 24:
+            lat_img.append(t2 - t1)
+            lat_both.append(t2 - t0)
+            parts.append(ctx.last_timing())
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
     st = ctx.get_observations()
     assert int((st[2] == 1).sum()) == world.M
     ctx.close()
@@ -392,7 +398,9 @@ def add_image_latency(np, capi, run, n=120):
     b = np.array(lat_both[10:]) * 1e6
     return {"unit": "us", "frames": len(a), "input": f"{cfg.cols}x{cfg.rows} bgr8 from pageable host memory, {world.L}-landmark map",
             "add_image_p50": round(float(np.percentile(a, 50)), 1), "add_image_p99": round(float(np.percentile(a, 99)), 1),
-            "encoder_plus_image_p50": round(float(np.percentile(b, 50)), 1), "encoder_plus_image_p99": round(float(np.percentile(b, 99)), 1)}
+            "encoder_plus_image_p50": round(float(np.percentile(b, 50)), 1), "encoder_plus_image_p99": round(float(np.percentile(b, 99)), 1),
+            "host_phases_p50": {k: round(float(np.percentile([p_[k] for p_ in parts[10:]], 50)), 1) for k in parts[0]},
+            "device_kernels_us_per_frame": {k: round(v[1] / max(v[0], 1) * 1e3, 1) for k, v in prof.items() if v[0]}}
 
 
 def host_fed_rate(np, run, H=100):

@@ -112,6 +112,9 @@ int aslam_add_encoder(aslam_ctx* ctx, double wl, double wr, double t_now_sec);
 /* ArucoSlam::addImage(const cv::Mat&) — aruco_slam.h:122, aruco_slam.cpp:76-287.  px is borrowed for the
  * call only (cv_bridge::toCvShare aliasing, aruco_slam_node.cpp:93); channels 1 (gray) or 3 (bgr8). */
 int aslam_add_image(aslam_ctx* ctx, const uint8_t* px, int rows, int cols, int channels, size_t step_bytes);
+/* host-clock breakdown of the last aslam_add_image in microseconds: upload of the borrowed pixels, enqueueing detection + pose,
+ * enqueueing the EKF step, waiting for the device, read-back of the overflow flags, total (instrumentation; no reference counterpart) */
+int aslam_get_last_timing(aslam_ctx* ctx, double out[6]);
 
 /* mu_ / sigma_ (aruco_slam.h:182-183).  sigma is written column-major with leading dimension N, exactly
  * Eigen::MatrixXd's layout.  Pass NULL for mu/sigma to query N only. */

@@ -158,6 +158,7 @@ inline hipemu_v4d __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipem
 }
 // lanes of a wave run in lockstep on the device; here they are coroutines, so code that relies on lockstep says so
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_sync(); }
+inline void __builtin_amdgcn_s_setprio(int) {}
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }

@@ -111,6 +111,10 @@ CASES = {
     # a visible set that slides by one landmark per frame: the union of a window grows past 20 landmarks (128-wide image)
     "sliding_set": (6, [(1, list(range(12)), False), (1, list(range(12, 24)), False), (1, list(range(24, 30)), False)]
                     + [(1, list(range(i, i + 12)), False) for i in range(0, 19)], 30),
+    # window -> window without anything in between: a long window is closed rather than widened, and the next one starts from P / mu_S
+    # derived from the first one's Lambda / Psi / psi while its flush is still running (overlapping sets: entries inside and outside S)
+    "window_to_window": (9, [(1, list(range(12)), False), (1, list(range(12, 24)), False), (1, list(range(24, 30)), False),
+                             (18, list(range(20)), False), (17, list(range(10, 30)), False), (17, list(range(5, 25)), False)], 30),
     # a frame without any observation inside a run (predict only)
     "empty_frame": (7, [(3, [0, 1, 2], False), (2, [], False), (3, [0, 2], False)], 3),
 }
@@ -148,6 +152,18 @@ def test_wide_window_50_corrections_per_frame():
     frames, exp = make_case(seed, groups, n_land)
     (mu, S), prof, worst = run_device(frames, exp, batch=len(frames), max_landmarks=60, max_updates=64)
     assert prof["k_ekf_win_chain"][0] > 0, "no window was formed"
+
+
+def test_early_start_equals_waiting_for_the_flush(monkeypatch):
+    """ASLAM_WIN_NO_EARLY makes every window wait for its own flush (the classic order): same results to rounding"""
+    seed, groups, n_land = CASES["window_to_window"]
+    frames, exp = make_case(seed, groups, n_land)
+    (mu, S), prof, _ = run_device(frames, exp, batch=len(frames))
+    assert prof["k_ekf_win_next"][0] >= 2, "no window started early"
+    monkeypatch.setenv("ASLAM_WIN_NO_EARLY", "1")
+    (mu2, S2), prof2, _ = run_device(frames, exp, batch=len(frames))
+    assert prof2["k_ekf_win_next"][0] == 0
+    assert np.allclose(mu, mu2, rtol=1e-10, atol=1e-12) and np.abs(S - S2).max() <= 1e-10 * np.abs(S).max()
 
 
 def test_windows_really_cover_subsets_and_sliding_sets():
