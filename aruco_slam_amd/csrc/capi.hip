@@ -918,8 +918,12 @@ int finalize_pending(aslam_ctx* c) {
         int piece = 0, log0 = 0;
         for (int k0 = 0, kn = 0; k0 < o.K; k0 += kn, piece++) {
             const int left = o.K - k0;
-            kn = std::min(c->win_piece, left);
-            if (kn == left && kn > kWinLastPiece) kn -= kWinLastPiece;
+            // pieces shrink towards the window's end (.., 4, 2, 2 frames): the replay of a piece starts when its chain ends, so the
+            // replay still running when the last chain piece ends - what the next window waits for - is that of two frames only
+            if (left > 2 * kWinLastPiece) kn = std::min(c->win_piece, left - 2 * kWinLastPiece);
+            else if (left > kWinLastPiece) kn = left - kWinLastPiece;
+            else kn = left;
+            kn = std::min(kn, c->win_piece);
             WinDesc sub = wd;
             sub.first_slot = o.frame + k0;
             sub.K = kn;

@@ -113,8 +113,9 @@ __device__ __forceinline__ void win_publish(const v4d (&acc)[RW][T], int p, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// T tiles per side, RW tile rows per worker wave: ceil(T / RW) worker waves + 1 prepare wave.  With T = 4 (2 x 2 rows) and T = 8
-// (3 + 3 + 2 rows) the prepare wave - the kernel's critical path - has a SIMD to itself (measured: -11 % per step).
+// T tiles per side, RW tile rows per worker wave: ceil(T / RW) worker waves + 1 prepare wave.  With T = 4 (2 x 2 rows on two
+// workers) the prepare wave - the kernel's critical path - has a SIMD to itself (measured: -11 % per step); at T = 8 the same idea
+// (3 + 3 + 2 rows on three workers) makes the workers the bottleneck (measured: +12 %), so it keeps one worker per SIMD.
 template <int T, int RW>
 __global__ __launch_bounds__(((T + RW - 1) / RW + 1) * 64) void k_ekf_win_chain(EkfState E, SlamParams sp, WinDesc wd, const ObsRaw* __restrict__ obs,
                                                                     const double* __restrict__ enc) {
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_next_fix(EkfState E, WinDesc pv
 // ---- host side --------------------------------------------------------------------------------------------------------
 void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc) {
     if (wd.T == 4) hipLaunchKernelGGL((k_ekf_win_chain<4, 2>), dim3(1), dim3(192), 0, st, E, sp, wd, obs, enc);
-    else if (wd.T == 8) hipLaunchKernelGGL((k_ekf_win_chain<8, 3>), dim3(1), dim3(256), 0, st, E, sp, wd, obs, enc);
+    else if (wd.T == 8) hipLaunchKernelGGL((k_ekf_win_chain<8, 2>), dim3(1), dim3(320), 0, st, E, sp, wd, obs, enc);   // (3 + 3 + 2 rows on three workers: measured slower)
     else hipLaunchKernelGGL((k_ekf_win_chain<12, 2>), dim3(1), dim3(448), 0, st, E, sp, wd, obs, enc);
 }
 void launch_ekf_win_gather(hipStream_t st, const EkfState& E, const WinDesc& wd) {
