@@ -137,7 +137,7 @@ def load_pmc(cfg_name, with_ekf):
         js = json.load(open(f))
         if js.get("config", "cfg2") == cfg_name and js.get("ekf", True) == with_ekf:
             per_launch = {k: int((2.0 * v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024)
-                          for k, v in js["kernels"].items()}
+                          for k, v in js["kernels"].items() if k.startswith("k_") and k != "k_render"}      # (k_render is the input generator)
             return os.path.basename(f), per_launch
     return None, {}
 

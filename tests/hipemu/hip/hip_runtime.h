@@ -300,11 +300,26 @@ template <class F> void run_grid(const char*, dim3 grid, dim3 block, F&& body) {
     g_gridDim = grid;
     const unsigned long long nblocks = (unsigned long long)grid.x * grid.y * grid.z;
     std::atomic<unsigned long long> next{0};
+    // HIPEMU_ORDER = reverse | shuffle: the order in which the workgroups of a launch are started (the device promises none): a
+    // kernel whose workgroups hand data to each other through global memory must give the same result in every order
+    static const int order_mode = [] { const char* e = std::getenv("HIPEMU_ORDER"); return !e ? 0 : e[0] == 'r' ? 1 : e[0] == 's' ? 2 : 0; }();
+    std::vector<unsigned long long> perm;
+    if (order_mode == 2) {
+        perm.resize(nblocks);
+        for (unsigned long long k = 0; k < nblocks; k++) perm[k] = k;
+        unsigned long long st = 0x9E3779B97F4A7C15ull ^ nblocks;
+        for (unsigned long long k = nblocks; k > 1; k--) {          // Fisher-Yates with a fixed xorshift: reproducible
+            st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            std::swap(perm[k - 1], perm[st % k]);
+        }
+    }
     auto worker = [&]() {
         std::vector<char> stacks;
         for (;;) {
             unsigned long long i = next.fetch_add(1);
             if (i >= nblocks) break;
+            if (order_mode == 1) i = nblocks - 1 - i;
+            else if (order_mode == 2) i = perm[i];
             unsigned bx = (unsigned)(i % grid.x), by = (unsigned)((i / grid.x) % grid.y), bz = (unsigned)(i / ((unsigned long long)grid.x * grid.y));
             F local = body;                      // per-OS-thread copy of the launch closure
             run_block(local, block, bx, by, bz, stacks);
