@@ -3,8 +3,8 @@
 //   cv::aruco::estimatePoseSingleMarkers -> solvePnP(SOLVEPNP_ITERATIVE) per marker (aruco_slam.cpp:314),
 //   the per-detection body of ArucoSlam::getObservations (aruco_slam.cpp:325-369): range gate, Rodrigues,
 //   (x, y, theta) observation, CalculateCovariance (aruco_slam.cpp:437-471) and the covariance gate.
-// k_pose: one workgroup per frame (marker list, _filterDetectedMarkers, cornerSubPix); k_pose_solve: one WAVEFRONT per marker
-// (6-parameter Levenberg-Marquardt on 8 residuals in fp64: the Jacobian entries spread over the lanes, J^T J on the matrix core).
+// One workgroup per frame; the pose solve is one lane per marker (6-parameter Levenberg-Marquardt on 8
+// residuals in fp64 — a latency-bound scalar chain; frames of the batch supply the parallelism).
 #include "common.h"
 #include "pose.h"
 #include <cfloat>
@@ -156,11 +156,12 @@ __device__ void project4(const double* p /*r,t*/, double hl, const CamParams& ca
 
 // solvePnP(ITERATIVE) for one marker: undistort -> 4-point homography (float inputs, Hartley-normalised)
 // -> R from h1, h2, h1 x h2 -> LM (<= 20 iterations, eps FLT_EPSILON, lambda = 10^k starting at k = -3)
-// the initial pose of solvePnP(ITERATIVE): undistort -> 4-point homography (float inputs, Hartley-normalised) -> R from h1, h2, h1 x h2
-__device__ void solve_marker_pose_init(const float* c8, float markerLength, const CamParams& cam, double* param) {
+__device__ void solve_marker_pose(const float* c8, float markerLength, const CamParams& cam, double* rvec, double* tvec) {
     const float hlf = markerLength / 2.f;
+    const double hl = (double)hlf;
     double m[8];
     for (int i = 0; i < 8; i++) m[i] = c8[i];
+    double param[6];
     {
         // cvUndistortPoints: 5 fixed-point iterations when a distortion vector is given
         float mn[8];
@@ -230,15 +231,6 @@ __device__ void solve_marker_pose_init(const float* c8, float markerLength, cons
         }
         rodrigues_inv(R, param);
     }
-}
-
-__device__ void solve_marker_pose(const float* c8, float markerLength, const CamParams& cam, double* rvec, double* tvec) {
-    const float hlf = markerLength / 2.f;
-    const double hl = (double)hlf;
-    double m[8];
-    for (int i = 0; i < 8; i++) m[i] = c8[i];
-    double param[6];
-    solve_marker_pose_init(c8, markerLength, cam, param);
 
     // CvLevMarq state machine
     double prevParam[6], J[48], err[8], JtJ[36], JtErr[6], proj[8];
@@ -285,135 +277,6 @@ __device__ void solve_marker_pose(const float* c8, float markerLength, const Cam
         prevErrNorm = errNorm;
         project4(param, hl, cam, proj, J);
         for (int i = 0; i < 8; i++) err[i] = proj[i] - m[i];
-    }
-    for (int i = 0; i < 3; i++) { rvec[i] = param[i]; tvec[i] = param[3 + i]; }
-}
-
-// ---- the same solve by ONE WAVEFRONT per marker ------------------------------------------------------------------------
-// The initial pose (undistort, 4-point homography, R from h1, h2, h1 x h2) is a short scalar sequence every lane runs identically.
-// The Levenberg-Marquardt iterations (<= 20, each a chain of: projection + Jacobian of the 8 residuals w.r.t. the 6 parameters,
-// J^T J and J^T e, a 6 x 6 solve, a projection for the new error) are spread over the wave:
-//   lane (lk = lane >> 4, li = lane & 15) owns the residuals r0 = lk and r1 = lk + 4 (same image coordinate of points lk >> 1 and
-//   2 + (lk >> 1)) and column li of [J | e]: it evaluates ITS two entries;
-//   [J | e]^T [J | e] - J^T J in rows / columns 0..5, J^T e in column 6 - is two v_mfma_f64_16x16x4_f64 whose A and B operands are
-//   the same register (A[i][k] = J[k][i] and B[k][j] = J[k][j] both live in lane 16 k + i resp. 16 k + j);
-//   the 6 x 6 system goes through LDS once and is solved by every lane identically (partial pivoting: data dependent, serial);
-//   the new error's eight squares are summed by two cross-lane steps.
-// Same CvLevMarq state machine, same accept / reject rule; the sums of J^T J are formed in the matrix core's order instead of
-// r = 0..7, so iterates agree with the lane-per-marker version to rounding (poses: 1e-4 is the bar, ~1e-12 in practice).
-__device__ __forceinline__ void lane_point(int pt, double hl, double& X, double& Y) {
-    X = (pt == 0 || pt == 3) ? -hl : hl;
-    Y = (pt < 2) ? hl : -hl;
-}
-// value (coordinate co of point pt) of the projection and, if J6 != nullptr, its derivatives w.r.t. the 6 parameters
-__device__ void project_entry(const double* p, const double* R, const double* dR, int pt, int co, double hl, const CamParams& cam, double& val, double* J6) {
-    double X, Y;
-    lane_point(pt, hl, X, Y);
-    const double* k = cam.k;
-    double x = R[0] * X + R[1] * Y + p[3];
-    double y = R[3] * X + R[4] * Y + p[4];
-    double z = R[6] * X + R[7] * Y + p[5];
-    z = z ? 1. / z : 1;
-    x *= z; y *= z;
-    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
-    const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
-    const double cd = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
-    val = co == 0 ? (x * cd + k[2] * a1 + k[3] * a2) * cam.fx + cam.cx : (y * cd + k[2] * a3 + k[3] * a1) * cam.fy + cam.cy;
-    if (J6) {
-        for (int j = 0; j < 6; j++) {
-            double dxd, dyd;
-            if (j < 3) {
-                const double dx0 = X * dR[j * 9] + Y * dR[j * 9 + 1];
-                const double dy0 = X * dR[j * 9 + 3] + Y * dR[j * 9 + 4];
-                const double dz0 = X * dR[j * 9 + 6] + Y * dR[j * 9 + 7];
-                dxd = z * (dx0 - x * dz0);
-                dyd = z * (dy0 - y * dz0);
-            } else {
-                dxd = j == 3 ? z : (j == 4 ? 0. : -x * z);
-                dyd = j == 3 ? 0. : (j == 4 ? z : -y * z);
-            }
-            const double dr2 = 2 * x * dxd + 2 * y * dyd;
-            const double dcd = (k[0] + 2 * k[1] * r2 + 3 * k[4] * r4) * dr2;
-            const double da1 = 2 * (x * dyd + y * dxd);
-            const double dmx = dxd * cd + x * dcd + k[2] * da1 + k[3] * (dr2 + 4 * x * dxd);
-            const double dmy = dyd * cd + y * dcd + k[2] * (dr2 + 4 * y * dyd) + k[3] * da1;
-            J6[j] = co == 0 ? cam.fx * dmx : cam.fy * dmy;
-        }
-    }
-}
-
-typedef double pose_v4d __attribute__((vector_size(4 * sizeof(double))));
-
-__device__ void solve_marker_pose_wave(const float* c8, float markerLength, const CamParams& cam, double* rvec, double* tvec, int lane,
-                                       double* sh /* 64 doubles of LDS owned by this wave */) {
-    const double hl = (double)(markerLength / 2.f);
-    double m[8];
-    for (int i = 0; i < 8; i++) m[i] = c8[i];
-    double param[6];
-    solve_marker_pose_init(c8, markerLength, cam, param);
-    const int lk = lane >> 4, li = lane & 15;
-    const int co = lk & 1, pt0 = lk >> 1, pt1 = 2 + (lk >> 1), r0 = lk, r1 = lk + 4;      // r = 2 pt + co
-    double prevParam[6];
-    double prevErrNorm = DBL_MAX, errNorm;
-    int lambdaLg10 = -3, iters = 0;
-    const double LOG10 = log(10.);
-    for (;;) {
-        // ---- this lane's two entries of [J | e] at `param` ----
-        double R[9], dR[27], J6[6], v0, v1, val;
-        rodrigues_fwd(param, R, dR);
-        project_entry(param, R, dR, pt0, co, hl, cam, val, J6);
-        const double e0 = val - m[r0];
-        v0 = li < 6 ? J6[li < 6 ? li : 0] : li == 6 ? e0 : 0.0;
-        project_entry(param, R, dR, pt1, co, hl, cam, val, J6);
-        const double e1 = val - m[r1];
-        v1 = li < 6 ? J6[li < 6 ? li : 0] : li == 6 ? e1 : 0.0;
-        if (iters == 0) {
-            double sq = li == 0 ? e0 * e0 + e1 * e1 : 0.0;                        // lanes (lk, 0): the eight squares, two per lane
-            sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
-            prevErrNorm = sqrt(__shfl(sq, 0));
-        }
-        // ---- [J | e]^T [J | e] on the matrix core: row i = lk + 4 reg, column li ----
-        pose_v4d acc = {0.0, 0.0, 0.0, 0.0};
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc, 0, 0, 0);
-        __builtin_amdgcn_wave_barrier();
-        if (li < 7) { sh[lk * 8 + li] = acc[0]; if (lk < 2) sh[(lk + 4) * 8 + li] = acc[1]; }
-        __builtin_amdgcn_wave_barrier();
-        double JtJ[36], JtErr[6];
-        for (int i = 0; i < 6; i++) {
-            for (int j = 0; j < 6; j++) JtJ[i * 6 + j] = sh[i * 8 + j];
-            JtErr[i] = sh[i * 8 + 6];
-            prevParam[i] = param[i];
-        }
-        bool done = false;
-        for (;;) {
-            {   // step(): solve (JtJ with diagonal * (1 + lambda)) x = JtErr ; param = prevParam - x
-                const double lambda = exp(lambdaLg10 * LOG10);
-                double A[36], b[6], x[6];
-                for (int i = 0; i < 36; i++) A[i] = JtJ[i];
-                for (int i = 0; i < 6; i++) { A[i * 6 + i] *= 1. + lambda; b[i] = JtErr[i]; }
-                solve_pp<6>(A, b, x);
-                for (int i = 0; i < 6; i++) param[i] = prevParam[i] - x[i];
-            }
-            double R2[9];
-            rodrigues_fwd(param, R2, nullptr);
-            double p0v, p1v;
-            project_entry(param, R2, nullptr, pt0, co, hl, cam, p0v, nullptr);
-            project_entry(param, R2, nullptr, pt1, co, hl, cam, p1v, nullptr);
-            const double d0 = p0v - m[r0], d1 = p1v - m[r1];
-            double sq = li == 0 ? d0 * d0 + d1 * d1 : 0.0;
-            sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
-            sq = __shfl(sq, 0);                                                    // (lanes li != 0 hold partial sums of zeros: take lane 0's)
-            errNorm = sqrt(sq);
-            if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) continue;
-            lambdaLg10 = max(lambdaLg10 - 1, -16);
-            double dn = 0, pn = 0;
-            for (int i = 0; i < 6; i++) { double d = param[i] - prevParam[i]; dn += d * d; pn += prevParam[i] * prevParam[i]; }
-            if (++iters >= 20 || sqrt(dn) / sqrt(pn) < (double)FLT_EPSILON) done = true;
-            break;
-        }
-        if (done) break;
-        prevErrNorm = errNorm;
     }
     for (int i = 0; i < 3; i++) { rvec[i] = param[i]; tvec[i] = param[3 + i]; }
 }
@@ -589,30 +452,16 @@ __global__ __launch_bounds__(128) void k_pose(const FinalCand* __restrict__ fina
         }
         __syncthreads();
     }
-    // the surviving markers (id, corners) in their final order; poses and observations: k_pose_solve, one wavefront per marker
     for (int k = tid; k < M; k += 128) {
         const int i = sOut[k];
-        Marker* mk = markers + (size_t)f * kMarkerMax + k;
-        mk->id = sId[i];
-        mk->pad = 0;
-        for (int j = 0; j < 8; j++) mk->c[j] = sC[i][j];
-    }
-}
+        Marker mk;
+        mk.id = sId[i];
+        mk.pad = 0;
+        for (int j = 0; j < 8; j++) mk.c[j] = sC[i][j];
+        solve_marker_pose(mk.c, (float)sp.marker_length, cam, mk.rvec, mk.tvec);
+        markers[(size_t)f * kMarkerMax + k] = mk;
 
-// estimatePoseSingleMarkers + the per-detection body of getObservations, one WAVEFRONT per marker (solve_marker_pose_wave);
-// workgroup (f, y) = frame f, four waves = marker slots 4 y .. 4 y + 3 of 32, a slot takes markers k = slot, slot + 32, ...
-constexpr int kPoseSlots = 32;
-__global__ __launch_bounds__(256) void k_pose_solve(Marker* __restrict__ markers, const unsigned* __restrict__ n_markers,
-                                                    ObsRaw* __restrict__ obs, CamParams cam, SlamParams sp) {
-    __shared__ double sh[4][64];
-    const int f = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int M = (int)min(n_markers[f], (unsigned)kMarkerMax);
-    for (int k = blockIdx.y * 4 + wave; k < M; k += kPoseSlots) {
-        Marker mk = markers[(size_t)f * kMarkerMax + k];
-        solve_marker_pose_wave(mk.c, (float)sp.marker_length, cam, mk.rvec, mk.tvec, lane, sh[wave]);
-
-        // getObservations loop body (aruco_slam.cpp:325-369), every lane identically; lane 0 stores
+        // getObservations loop body (aruco_slam.cpp:325-369)
         ObsRaw o;
         o.id = mk.id;
         o.valid = 1;
@@ -644,17 +493,13 @@ __global__ __launch_bounds__(256) void k_pose_solve(Marker* __restrict__ markers
         o.r[1] = object_error * sp.R_y + 1e-2;
         o.r[2] = object_error * sp.R_theta + 1e-3;
         if (sqrt(o.r[0] * o.r[0] + o.r[1] * o.r[1] + o.r[2] * o.r[2]) > 1) o.valid = 0;   // aruco_slam.cpp:367
-        if (lane == 0) {
-            markers[(size_t)f * kMarkerMax + k] = mk;
-            obs[(size_t)f * kMarkerMax + k] = o;
-        }
+        obs[(size_t)f * kMarkerMax + k] = o;
     }
 }
 
 void launch_pose(hipStream_t st, int nframes, const FinalCand* finals, const unsigned* n_final, Marker* markers,
                  unsigned* n_markers, ObsRaw* obs, const CamParams& cam, const SlamParams& sp, Counters* ctr, const RefineCfg& rf) {
     hipLaunchKernelGGL(k_pose, dim3(nframes), dim3(128), 0, st, finals, n_final, markers, n_markers, obs, cam, sp, ctr, rf);
-    hipLaunchKernelGGL(k_pose_solve, dim3(nframes, kPoseSlots / 4), dim3(256), 0, st, markers, n_markers, obs, cam, sp);
 }
 
 } // namespace aslam
