@@ -501,21 +501,30 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd, in
     const double* logp = E.d_win_log + (size_t)wd.log0 * ls;
     double* tlog = E.d_win_tlog + (size_t)wd.log0 * ts + WBW * b;
     const int lt = tid - 64;                                       // loading thread index (waves 1..3)
-    double pf[RPT];
+    // the log was written moments ago by another CU: a record takes longer to arrive than a step lasts, so the loading waves keep
+    // PFD records in flight (registers), one per step of the unrolled loop
+    constexpr int PFD = 3;
+    double pf[PFD][RPT];
 #pragma unroll
-    for (int q = 0; q < RPT; q++) { const int e = lt + 192 * q; pf[q] = (lt >= 0 && e < REC && nsteps > 0) ? logp[e] : 0.0; }
+    for (int u = 0; u < PFD; u++)
+#pragma unroll
+        for (int q = 0; q < RPT; q++) { const int e = lt + 192 * q; pf[u][q] = (lt >= 0 && e < REC && u < nsteps) ? logp[(size_t)u * ls + e] : 0.0; }
     for (int e = tid; e < 2 * 4 * WBW; e += 256) (&sT[0][0][0])[e] = 0.0;
     __syncthreads();
-    for (int n = 0; n < nsteps; n++) {
+    for (int n0 = 0; n0 < nsteps; n0 += PFD) {
+#pragma unroll
+      for (int u = 0; u < PFD; u++) {
+        const int n = n0 + u;
+        if (n >= nsteps) break;
         double* rec = sRec[n & 1];
         double (*tt)[WBW] = sT[n & 1];
         if (lt >= 0) {
 #pragma unroll
-            for (int q = 0; q < RPT; q++) { const int e = lt + 192 * q; if (e < REC) rec[e] = pf[q]; }
-            if (n + 1 < nsteps) {                                   // in flight while this step is applied
-                const double* nx = logp + (size_t)(n + 1) * ls;
+            for (int q = 0; q < RPT; q++) { const int e = lt + 192 * q; if (e < REC) rec[e] = pf[u][q]; }
+            if (n + PFD < nsteps) {                                 // in flight while the next PFD steps are applied
+                const double* nx = logp + (size_t)(n + PFD) * ls;
 #pragma unroll
-                for (int q = 0; q < RPT; q++) { const int e = lt + 192 * q; pf[q] = e < REC ? nx[e] : 0.0; }
+                for (int q = 0; q < RPT; q++) { const int e = lt + 192 * q; pf[u][q] = e < REC ? nx[e] : 0.0; }
             }
         }
         ASLAM_LDS_BARRIER();
@@ -566,6 +575,7 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd, in
                 sLam[r][c] += rec[r] * t0 + rec[SP + r] * t1 + rec[2 * SP + r] * t2;
             }
         }
+      }
     }
     __syncthreads();
     for (int e = tid; e < SP * WBW; e += 256) { const int r = e / WBW, c = e % WBW; Lam[(size_t)r * SP + WBW * b + c] = sLam[r][c]; }
@@ -700,8 +710,8 @@ __global__ __launch_bounds__(256) void k_ekf_win_gather(EkfState E, WinDesc wd) 
         const int base = (t - 3) / 3 * 3 + 3;
         for (int a = 0; a < nS; a++) if (wd.li[a] == base) pos = 3 + 3 * a + (t - base);
     }
-    E.d_win_sidx[t] = pos;
-    for (int p = 0; p < SP; p++) E.d_Wt[(size_t)p * ld + t] = p < s ? E.d_sigma[(size_t)win_state_index(wd, p) * ld + t] : 0.0;
+    if (blockIdx.y == 0) E.d_win_sidx[t] = pos;
+    for (int p = blockIdx.y; p < SP; p += gridDim.y) E.d_Wt[(size_t)p * ld + t] = p < s ? E.d_sigma[(size_t)win_state_index(wd, p) * ld + t] : 0.0;
 }
 
 // ---- early start of the next window -----------------------------------------------------------------------------------
@@ -726,8 +736,8 @@ __global__ __launch_bounds__(256) void k_ekf_win_next_gather(EkfState E, WinDesc
         E.d_win_next_idx[a] = pa;
         if (a == 0) E.d_win_next_idx[SPm] = nx.nS;
         mu2[a] = E.d_mu[ia];
-        for (int p = 0; p < SPp; p++) Vg[(size_t)p * SPm + a] = pa < 0 ? E.d_Wt[(size_t)p * ld + ia] : 0.0;
     }
+    for (int p = blockIdx.y; p < SPp; p += gridDim.y) Vg[(size_t)p * SPm + a] = pa < 0 ? E.d_Wt[(size_t)p * ld + ia] : 0.0;
     for (int b = blockIdx.y; b < s2; b += gridDim.y) Ptmp[(size_t)b * SPm + a] = E.d_sigma[(size_t)win_state_index(nx, b) * ld + ia];
 }
 __global__ __launch_bounds__(256) void k_ekf_win_next_fix(EkfState E, WinDesc pv, WinDesc nx) {
@@ -757,7 +767,7 @@ void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& s
     else hipLaunchKernelGGL((k_ekf_win_chain<12, 2>), dim3(1), dim3(448), 0, st, E, sp, wd, obs, enc);
 }
 void launch_ekf_win_gather(hipStream_t st, const EkfState& E, const WinDesc& wd) {
-    hipLaunchKernelGGL(k_ekf_win_gather, dim3((E.ld + 255) / 256), dim3(256), 0, st, E, wd);
+    hipLaunchKernelGGL(k_ekf_win_gather, dim3((E.ld + 255) / 256, 16), dim3(256), 0, st, E, wd);       // y: rows of Y_0 in turn (one load in flight per thread otherwise)
 }
 static void launch_thin(hipStream_t st, const EkfState& E, const WinDesc& wd, int ncols) {
     const int SP = 16 * wd.T, nb = (ncols + 63) / 64;
@@ -767,7 +777,7 @@ static void launch_thin(hipStream_t st, const EkfState& E, const WinDesc& wd, in
 }
 void launch_ekf_win_next(hipStream_t st, const EkfState& E, const WinDesc& pv, const WinDesc& nx) {
     const int SPm = E.win_sp_max, s2 = 3 + 3 * nx.nS, SPn = 16 * nx.T;
-    hipLaunchKernelGGL(k_ekf_win_next_gather, dim3((s2 + 255) / 256, 16), dim3(256), 0, st, E, pv, nx);
+    hipLaunchKernelGGL(k_ekf_win_next_gather, dim3((s2 + 255) / 256, 64), dim3(256), 0, st, E, pv, nx);
     // the miniature state the previous window's thin products and the Sigma pass run on: N := s', Sigma := Sigma_old[S', S']
     EkfState E2 = E;
     E2.ld = SPm;
