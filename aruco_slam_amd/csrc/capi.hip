@@ -860,14 +860,16 @@ int finalize_pending(aslam_ctx* c) {
         if (o.K == 0) c->plan_stats[1]++;
         else { c->plan_stats[0] += o.K; c->plan_stats[2]++; }
     }
-    // Streams: sa = the EKF stream (chain pieces, per-frame chains), sb = replay (scan + Psi per piece), the window's gather and its
-    // flush.  A window that is followed by another window does not wait for its own flush: the next window's P and mu_S are
+    // Streams: sa = the EKF stream (chain pieces with their replay, per-frame chains), sb = the window's gather and its flush.  A window that is followed by another window does not wait for its own flush: the next window's P and mu_S are
     // derived from this window's small results (launch_ekf_win_next, on sa) while the pass over Sigma runs on sb; only the next
     // window's LAST piece (which writes mu back) and whatever is not a window wait for the flush.
     hipStream_t sa = c->stream_ekf, sb = c->stream_win;
     auto new_event = [&]() { return c->ev_win[c->ev_win_next++ & 63]; };
-    struct { bool active = false; WinDesc wd{}; hipEvent_t ev_psi = nullptr; } pf;      // the previous window's flush, not yet enqueued
+    struct { bool active = false; WinDesc wd{}; } pf;               // the previous window's flush, not yet enqueued
     auto flush_now = [&](const WinDesc& fwd) -> int {                                    // classic order: flush, then the EKF stream goes on
+        hipEvent_t evr = new_event();
+        HIP_TRY(c, hipEventRecord(evr, sa));                         // the window's replay (Lambda, Psi, psi) is complete
+        HIP_TRY(c, hipStreamWaitEvent(sb, evr, 0));
         prof_begin(c, P_EKF_WIN_FLUSH, sb);
         launch_ekf_win_flush(sb, c->ekf, fwd);
         prof_end(c);
@@ -894,8 +896,7 @@ int finalize_pending(aslam_ctx* c) {
         for (int a = 0; a < wd.nS; a++) wd.li[a] = (short)(3 + 3 * o.S[a]);
         hipEvent_t ev_prev_flush = nullptr;
         if (pf.active) {
-            HIP_TRY(c, hipStreamWaitEvent(sa, pf.ev_psi, 0));        // the previous window's Lambda, Psi, psi are complete
-            prof_begin(c, P_EKF_WIN_NEXT, sa);
+            prof_begin(c, P_EKF_WIN_NEXT, sa);                       // (the previous window's Lambda, Psi, psi are complete: same stream)
             launch_ekf_win_next(sa, c->ekf, pf.wd, wd);
             prof_end(c);
             hipEvent_t ev_next = new_event();
@@ -914,42 +915,49 @@ int finalize_pending(aslam_ctx* c) {
             HIP_TRY(c, hipStreamWaitEvent(sb, ev, 0));               // Sigma as the EKF stream leaves it
         }
         launch_ekf_win_gather(sb, c->ekf, wd);                       // Y_0 of this window (behind the previous window's flush: same stream)
-        // The chain of whatever follows waits for this window's last replay: the last piece is kept short (kWinLastPiece frames).
-        int piece = 0, log0 = 0;
-        for (int k0 = 0, kn = 0; k0 < o.K; k0 += kn, piece++) {
-            const int left = o.K - k0;
-            // pieces shrink towards the window's end (.., 4, 2, 2 frames): the replay of a piece starts when its chain ends, so the
-            // replay still running when the last chain piece ends - what the next window waits for - is that of two frames only
-            if (left > 2 * kWinLastPiece) kn = std::min(c->win_piece, left - 2 * kWinLastPiece);
-            else if (left > kWinLastPiece) kn = left - kWinLastPiece;
-            else kn = left;
-            kn = std::min(kn, c->win_piece);
-            WinDesc sub = wd;
-            sub.first_slot = o.frame + k0;
-            sub.K = kn;
-            sub.piece = piece;
-            sub.log0 = log0;
-            sub.last = k0 + kn == o.K ? 1 : 0;
-            int nsteps = 0;
-            for (int k = 0; k < kn; k++) nsteps += 1 + c->h_win_frames[sub.first_slot + k].m;
-            if (sub.last && ev_prev_flush) HIP_TRY(c, hipStreamWaitEvent(sa, ev_prev_flush, 0));   // mu_S goes back into the state: after the previous flush's mu_R pass
-            prof_begin(c, P_EKF_WIN_CHAIN, sa);
-            launch_ekf_win_chain(sa, c->ekf, c->sp, sub, c->d_obs, c->d_enc);
+        // The pieces of the window, back to back on sa: launch i carries the chain of piece i, the replay of piece i - 1 and the Psi
+        // product of piece i - 2 (ekf_window.hip: k_ekf_win_step), so nothing but the stream orders them; two more launches drain
+        // the replay.  What follows the window waits for that drain: the pieces shrink towards the end (.., 4, 2, 2 frames).
+        struct Piece { WinDesc sub; int nsteps; };
+        std::vector<Piece> pieces;
+        {
+            int piece = 0, log0 = 0;
+            for (int k0 = 0, kn = 0; k0 < o.K; k0 += kn, piece++) {
+                const int left = o.K - k0;
+                if (left > 2 * kWinLastPiece) kn = std::min(c->win_piece, left - 2 * kWinLastPiece);
+                else if (left > kWinLastPiece) kn = left - kWinLastPiece;
+                else kn = left;
+                kn = std::min(kn, c->win_piece);
+                Piece pc;
+                pc.sub = wd;
+                pc.sub.first_slot = o.frame + k0;
+                pc.sub.K = kn;
+                pc.sub.piece = piece;
+                pc.sub.log0 = log0;
+                pc.sub.last = k0 + kn == o.K ? 1 : 0;
+                pc.nsteps = 0;
+                for (int k = 0; k < kn; k++) pc.nsteps += 1 + c->h_win_frames[pc.sub.first_slot + k].m;
+                log0 += pc.nsteps;
+                pieces.push_back(pc);
+            }
+        }
+        const int P = (int)pieces.size();
+        for (int i = 0; i < P + 2; i++) {
+            WinDesc cw = wd;
+            cw.K = 0;
+            if (i < P) cw = pieces[i].sub;
+            const Piece* ps = (i >= 1 && i <= P) ? &pieces[i - 1] : nullptr;
+            const Piece* pq = (i >= 2) ? &pieces[i - 2] : nullptr;
+            if (i < P && cw.last && ev_prev_flush) HIP_TRY(c, hipStreamWaitEvent(sa, ev_prev_flush, 0));   // mu_S goes back into the state: after the previous flush's mu_R pass
+            prof_begin(c, i < P ? P_EKF_WIN_CHAIN : P_EKF_WIN_SCAN, sa);
+            launch_ekf_win_step(sa, c->ekf, c->sp, cw, c->d_obs, c->d_enc, ps ? ps->sub.piece : 0, ps ? ps->sub.log0 : 0, ps ? ps->nsteps : 0,
+                                pq ? pq->sub.piece : 0, pq ? pq->sub.log0 : 0, pq ? pq->nsteps : 0);
             prof_end(c);
-            hipEvent_t ev = new_event();
-            HIP_TRY(c, hipEventRecord(ev, sa));
-            HIP_TRY(c, hipStreamWaitEvent(sb, ev, 0));
-            prof_begin(c, P_EKF_WIN_SCAN, sb);
-            launch_ekf_win_scan(sb, c->ekf, sub, nsteps);
-            prof_end(c);
-            log0 += nsteps;
         }
         HIP_TRY(c, hipGetLastError());
         const bool next_is_window = oi + 1 < ops.size() && ops[oi + 1].K > 0 && !c->win_no_early;
         if (next_is_window) {
             pf.active = true; pf.wd = wd;
-            pf.ev_psi = new_event();
-            HIP_TRY(c, hipEventRecord(pf.ev_psi, sb));
         } else {
             int r = flush_now(wd);
             if (r) return r;

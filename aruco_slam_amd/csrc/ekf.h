@@ -100,12 +100,13 @@ void launch_ekf_small(hipStream_t st, const EkfState& E);
 void launch_ekf_T(hipStream_t st, const EkfState& E);
 void launch_ekf_export_map(hipStream_t st, const EkfState& E);
 int ekf_win_tiles(int nS);             // T for a set of nS landmarks (4, 8 or 12)
-// obs / enc: the context's per-slot arrays
-void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc);
+// one launch of a window: the chain of piece wd (wd.K == 0: none), the replay (scan) of piece s_*, the Psi product of piece q_*
+// (nsteps == 0: none); obs / enc: the context's per-slot arrays
+void launch_ekf_win_step(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc,
+                         int s_piece, int s_log0, int s_nsteps, int q_piece, int q_log0, int q_nsteps);
 void launch_ekf_win_gather(hipStream_t st, const EkfState& E, const WinDesc& wd);               // Y_0 = rows S of Sigma, position table
 // P and mu_S of the NEXT window (set nx) from the previous window's (pv) P_K, Lambda, Psi, psi, Y_0 and the not yet flushed Sigma / mu
 void launch_ekf_win_next(hipStream_t st, const EkfState& E, const WinDesc& pv, const WinDesc& nx);
-void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd, int nsteps);      // + Psi accumulation of the piece
 void launch_ekf_win_flush(hipStream_t st, const EkfState& E, const WinDesc& wd);                 // thin products, Sigma pass, rows / columns of S
 
 } // namespace aslam

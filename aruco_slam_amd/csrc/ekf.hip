@@ -1333,7 +1333,7 @@ hipError_t ekf_alloc(EkfState& E, int max_landmarks, int max_slots, int max_upda
     E.win_steps_max = kWinFrames * (1 + std::min(max_updates_per_frame, kWinCorrMax));
     A(dalloc(&E.d_win_log, (size_t)E.win_steps_max * (3 * E.win_sp_max + kWinHdr) + 512));
     A(dalloc(&E.d_win_tlog, (size_t)E.win_steps_max * 8 * E.win_sp_max));
-    A(dalloc(&E.d_win_small, (size_t)4 * E.win_sp_max * E.win_sp_max + 3 * E.win_sp_max));
+    A(dalloc(&E.d_win_small, (size_t)6 * E.win_sp_max * E.win_sp_max + 4 * E.win_sp_max));
     A(dalloc(&E.d_win_next, (size_t)4 * E.win_sp_max * E.win_sp_max));
     A(dalloc(&E.d_win_next_idx, (size_t)E.win_sp_max + 4));
     A(dalloc(&E.d_win_sidx, ld));

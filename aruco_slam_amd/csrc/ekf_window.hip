@@ -54,10 +54,11 @@ __host__ __device__ inline int win_tlog_stride(int T) { return 8 * 16 * T; }
 enum { WH_TYPE = 0, WH_POS = 1, WH_SI = 2, WH_ZE = 11, WH_C = 14, WH_S = 15, WH_G02 = 16, WH_G12 = 17, WH_A = 18, WH_B = 19 };
 // d_win_small: images of the window, each SPm x SPm at most (SPm = E.win_sp_max), stored with the window's own row stride SP
 __host__ __device__ inline size_t wsm_P(int SPm, int par) { return (size_t)par * SPm * SPm; }             // P image of window parity par
-__host__ __device__ inline size_t wsm_LAM(int SPm) { return (size_t)2 * SPm * SPm; }
-__host__ __device__ inline size_t wsm_PSI(int SPm) { return (size_t)3 * SPm * SPm; }
-__host__ __device__ inline size_t wsm_psi(int SPm) { return (size_t)4 * SPm * SPm; }
-__host__ __device__ inline size_t wsm_MU(int SPm, int par) { return (size_t)4 * SPm * SPm + (size_t)(1 + par) * SPm; }   // mu_S image
+__host__ __device__ inline size_t wsm_LAM(int SPm, int par) { return (size_t)(2 + par) * SPm * SPm; }      // Lambda / Psi / psi: also per parity (the flush of a
+__host__ __device__ inline size_t wsm_PSI(int SPm, int par) { return (size_t)(4 + par) * SPm * SPm; }      // window reads them while the next window's replay writes its own)
+__host__ __device__ inline size_t wsm_psi(int SPm, int par) { return (size_t)6 * SPm * SPm + (size_t)par * SPm; }
+__host__ __device__ inline size_t wsm_MU(int SPm, int par) { return (size_t)6 * SPm * SPm + (size_t)(2 + par) * SPm; }   // mu_S image
+__host__ __device__ inline size_t wsm_doubles(int SPm) { return (size_t)6 * SPm * SPm + (size_t)4 * SPm; }
 
 int ekf_win_tiles(int nS) { return nS <= 20 ? 4 : nS <= 41 ? 8 : 12; }
 
@@ -116,19 +117,25 @@ __device__ __forceinline__ void win_publish(const v4d (&acc)[RW][T], int p, int 
 // T tiles per side, RW tile rows per worker wave: ceil(T / RW) worker waves + 1 prepare wave.  With T = 4 (2 x 2 rows on two
 // workers) the prepare wave - the kernel's critical path - has a SIMD to itself (measured: -11 % per step); at T = 8 the same idea
 // (3 + 3 + 2 rows on three workers) makes the workers the bottleneck (measured: +12 %), so it keeps one worker per SIMD.
+template <int T> struct WinChainLds {
+    static constexpr int SP = 16 * T, SPP = SP + 16, NSMAX = kWinPieceMax * 64;
+    double sA[2][4][SPP];                  // a step's A operand rows  Aop[k][row]   (P += Aop^T Bop)
+    double sB[2][4][SPP];                  // ... and B operand rows   Bop[k][column]
+    double sPub[2][6][SPP];                // rows 0..2 (pose) and the landmark rows of the step after next
+    double sMu[SPP];                       // prepare wave's scratch: mu_S by position
+    int sS[SP];
+    int sOff[kWinPieceMax + 1];
+    unsigned char sPos[NSMAX], sIdx[NSMAX], sFrm[NSMAX];   // per step: landmark position (255 = predict), correction index, frame
+};
 template <int T, int RW>
-__global__ __launch_bounds__(((T + RW - 1) / RW + 1) * 64) void k_ekf_win_chain(EkfState E, SlamParams sp, WinDesc wd, const ObsRaw* __restrict__ obs,
-                                                                    const double* __restrict__ enc) {
+__device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* __restrict__ obs,
+                               const double* __restrict__ enc, unsigned char* smem) {
     constexpr int SP = 16 * T, SPP = SP + 16, NC = SP / 64;       // SPP: operand rows lk and lk + 1 fall on opposite halves of the bank row
     constexpr int NWK = (T + RW - 1) / RW, NT = (NWK + 1) * 64;
-    constexpr int NSMAX = kWinPieceMax * 64;
-    __shared__ __align__(16) double sA[2][4][SPP];                 // a step's A operand rows  Aop[k][row]   (P += Aop^T Bop)
-    __shared__ __align__(16) double sB[2][4][SPP];                 // ... and B operand rows   Bop[k][column]
-    __shared__ __align__(16) double sPub[2][6][SPP];               // rows 0..2 (pose) and the landmark rows of the step after next
-    __shared__ double sMu[SPP];                                    // prepare wave's scratch: mu_S by position
-    __shared__ int sS[SP];
-    __shared__ unsigned char sPos[NSMAX], sIdx[NSMAX], sFrm[NSMAX];   // per step: landmark position (255 = predict), correction index, frame
-    __shared__ int sOff[kWinPieceMax + 1];
+    WinChainLds<T>& L = *reinterpret_cast<WinChainLds<T>*>(smem);
+    auto& sA = L.sA; auto& sB = L.sB; auto& sPub = L.sPub; auto& sMu = L.sMu; auto& sS = L.sS; auto& sOff = L.sOff;
+    auto& sPos = L.sPos; auto& sIdx = L.sIdx; auto& sFrm = L.sFrm;
+    if (threadIdx.x >= NT) return;                                  // (the launch's block is sized for its widest role)
     const int tid = threadIdx.x;
     const int nS = wd.nS, s = 3 + 3 * nS;
     const int ld = E.ld;
@@ -481,17 +488,25 @@ __global__ __launch_bounds__(((T + RW - 1) / RW + 1) * 64) void k_ekf_win_chain(
 // Per step: t = H Lambda (3 x WBW), Lambda += Aop^T t, psi += t^T (S^-1 ze); t and u = S^-1 t are logged for the Psi product.
 // Two LDS barriers per step.  Wave 0 forms t (and then u, for the log) and is the only wave that stores, waves 1..3 are the only
 // ones that load (the next step's record, one step ahead): no wave ever waits for its own stores to be acknowledged.
+struct WinReplay { int piece, log0, nsteps, wpar; };              // the piece a replay role works on
+template <int T> struct WinScanLds {
+    static constexpr int SP = 16 * T, REC = 3 * SP + kWinHdr;
+    double sLam[SP][WBW + 1];
+    double sRec[2][REC];
+    double sT[2][4][WBW];                  // t (row 3 stays zero)
+};
 template <int T>
-__global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd, int nsteps) {
+__device__ void win_scan_role(const EkfState& E, const WinReplay& wd, int b, unsigned char* smem) {
     constexpr int SP = 16 * T, EPT = SP * WBW / 256, REC = 3 * SP + kWinHdr;
     constexpr int RPT = (REC + 191) / 192;                         // record doubles per loading thread
-    __shared__ double sLam[SP][WBW + 1];
-    __shared__ double sRec[2][REC];
-    __shared__ double sT[2][4][WBW];                               // t (row 3 stays zero)
-    const int tid = threadIdx.x, b = blockIdx.x;
+    WinScanLds<T>& L = *reinterpret_cast<WinScanLds<T>*>(smem);
+    auto& sLam = L.sLam; auto& sRec = L.sRec; auto& sT = L.sT;
+    if (threadIdx.x >= 256) return;
+    const int nsteps = wd.nsteps;
+    const int tid = threadIdx.x;
     const int ls = win_log_stride(T), ts = win_tlog_stride(T);
-    double* Lam = E.d_win_small + wsm_LAM(E.win_sp_max);
-    double* psi = E.d_win_small + wsm_psi(E.win_sp_max);
+    double* Lam = E.d_win_small + wsm_LAM(E.win_sp_max, wd.wpar);
+    double* psi = E.d_win_small + wsm_psi(E.win_sp_max, wd.wpar);
     for (int e = tid; e < SP * WBW; e += 256) {
         const int r = e / WBW, c = e % WBW;
         sLam[r][c] = wd.piece ? Lam[(size_t)r * SP + WBW * b + c] : (r == WBW * b + c ? 1.0 : 0.0);
@@ -586,13 +601,14 @@ __global__ __launch_bounds__(256) void k_ekf_win_scan(EkfState E, WinDesc wd, in
 // Psi (+)= sum over the piece's steps of t^T u on the f64 matrix cores: workgroup = tile row, wave w = tile columns w, w + 4, ...
 // The operands come straight from the t / u log (L2): four steps are fetched ahead of the four products.
 template <int T>
-__global__ __launch_bounds__(256) void k_ekf_win_psi(EkfState E, WinDesc wd, int nsteps) {
+__device__ void win_psi_role(const EkfState& E, const WinReplay& wd, int tr) {
     constexpr int SP = 16 * T, TW = (T + 3) / 4, UN = 4;
+    if (threadIdx.x >= 256) return;
+    const int nsteps = wd.nsteps;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int li = lane & 15, lk = lane >> 4;
-    const int tr = blockIdx.x;
     const int ts = win_tlog_stride(T);
-    double* Psi = E.d_win_small + wsm_PSI(E.win_sp_max);
+    double* Psi = E.d_win_small + wsm_PSI(E.win_sp_max, wd.wpar);
     const double* tlog = E.d_win_tlog + (size_t)wd.log0 * ts;
     v4d acc[TW];
 #pragma unroll
@@ -629,6 +645,23 @@ __global__ __launch_bounds__(256) void k_ekf_win_psi(EkfState E, WinDesc wd, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// One launch = the chain of piece i (workgroup 0), the replay of piece i - 1 on Lambda (the next SP / 8 workgroups) and the Psi
+// product of piece i - 2 (the last T workgroups).  The three depend on each other only through the PREVIOUS launch (the log of
+// piece i - 1 is complete when this launch starts: same stream), so no events are needed between the pieces of a window and the
+// replay is hidden behind the chain: with one event per piece the EKF alone ran 14 % slower (cfg2).
+template <int T, int RW>
+__global__ __launch_bounds__(((T + RW - 1) / RW + 1) * 64 > 256 ? ((T + RW - 1) / RW + 1) * 64 : 256)
+void k_ekf_win_step(EkfState E, SlamParams sp, WinDesc wd, WinReplay rs, WinReplay rq, const ObsRaw* __restrict__ obs, const double* __restrict__ enc) {
+    constexpr size_t kLds = sizeof(WinChainLds<T>) > sizeof(WinScanLds<T>) ? sizeof(WinChainLds<T>) : sizeof(WinScanLds<T>);
+    __shared__ __align__(16) unsigned char smem[kLds];
+    constexpr int NSCAN = 16 * T / WBW;
+    const int bx = blockIdx.x;
+    if (bx == 0) { if (wd.K > 0) win_chain_role<T, RW>(E, sp, wd, obs, enc, smem); }
+    else if (bx <= NSCAN) { if (rs.nsteps > 0) win_scan_role<T>(E, rs, bx - 1, smem); }
+    else if (rq.nsteps > 0) win_psi_role<T>(E, rq, bx - 1 - NSCAN);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // U = Psi Y_0 -> d_T and Y_K = Lambda Y_0 -> d_V (both SP x N) as ONE product [Psi; Lambda] (2 SP x SP) . Y_0 (SP x N) on the matrix
 // cores: workgroup (x, y) = 64 columns of Sigma x 64 rows of the stacked matrix, depth in chunks of 64 staged through LDS (both
 // operands, coalesced), wave w = 16 of the columns x all 64 rows.  Workgroups with y = 0 also add Y_0^T psi to their 64 entries
@@ -647,8 +680,8 @@ __global__ __launch_bounds__(256) void k_ekf_win_thin(EkfState E, WinDesc wd) {
     const int r0 = blockIdx.y * 64;                                 // row of the stacked matrix
     const bool lam = r0 >= SP;
     const int s = 3 + 3 * wd.nS;
-    const double* M = E.d_win_small + (lam ? wsm_LAM(E.win_sp_max) : wsm_PSI(E.win_sp_max)) + (size_t)(lam ? r0 - SP : r0) * SP;
-    const double* psi = E.d_win_small + wsm_psi(E.win_sp_max);
+    const double* M = E.d_win_small + (lam ? wsm_LAM(E.win_sp_max, wd.wpar) : wsm_PSI(E.win_sp_max, wd.wpar)) + (size_t)(lam ? r0 - SP : r0) * SP;
+    const double* psi = E.d_win_small + wsm_psi(E.win_sp_max, wd.wpar);
     double* out = lam ? E.d_V : E.d_T;
     const int orow = lam ? r0 - SP : r0;
     v4d acc[4];
@@ -761,10 +794,13 @@ __global__ __launch_bounds__(256) void k_ekf_win_next_fix(EkfState E, WinDesc pv
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
-void launch_ekf_win_chain(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc) {
-    if (wd.T == 4) hipLaunchKernelGGL((k_ekf_win_chain<4, 2>), dim3(1), dim3(192), 0, st, E, sp, wd, obs, enc);
-    else if (wd.T == 8) hipLaunchKernelGGL((k_ekf_win_chain<8, 2>), dim3(1), dim3(320), 0, st, E, sp, wd, obs, enc);   // (3 + 3 + 2 rows on three workers: measured slower)
-    else hipLaunchKernelGGL((k_ekf_win_chain<12, 2>), dim3(1), dim3(448), 0, st, E, sp, wd, obs, enc);
+void launch_ekf_win_step(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc,
+                         int s_piece, int s_log0, int s_nsteps, int q_piece, int q_log0, int q_nsteps) {
+    const WinReplay rs{s_piece, s_log0, s_nsteps, wd.wpar}, rq{q_piece, q_log0, q_nsteps, wd.wpar};
+    const int nb = 1 + 16 * wd.T / WBW + wd.T;
+    if (wd.T == 4) hipLaunchKernelGGL((k_ekf_win_step<4, 2>), dim3(nb), dim3(256), 0, st, E, sp, wd, rs, rq, obs, enc);
+    else if (wd.T == 8) hipLaunchKernelGGL((k_ekf_win_step<8, 2>), dim3(nb), dim3(320), 0, st, E, sp, wd, rs, rq, obs, enc);   // (3 + 3 + 2 rows on three workers: measured slower)
+    else hipLaunchKernelGGL((k_ekf_win_step<12, 2>), dim3(nb), dim3(448), 0, st, E, sp, wd, rs, rq, obs, enc);
 }
 void launch_ekf_win_gather(hipStream_t st, const EkfState& E, const WinDesc& wd) {
     hipLaunchKernelGGL(k_ekf_win_gather, dim3((E.ld + 255) / 256, 16), dim3(256), 0, st, E, wd);       // y: rows of Y_0 in turn (one load in flight per thread otherwise)
@@ -791,18 +827,6 @@ void launch_ekf_win_next(hipStream_t st, const EkfState& E, const WinDesc& pv, c
     launch_thin(st, E2, pv, s2);
     launch_ekf_update_mfma(st, E2, 16 * pv.T);
     hipLaunchKernelGGL(k_ekf_win_next_fix, dim3((SPn + 255) / 256, 16), dim3(256), 0, st, E, pv, nx);
-}
-void launch_ekf_win_scan(hipStream_t st, const EkfState& E, const WinDesc& wd, int nsteps) {
-    if (wd.T == 4) {
-        hipLaunchKernelGGL(k_ekf_win_scan<4>, dim3(64 / WBW), dim3(256), 0, st, E, wd, nsteps);
-        hipLaunchKernelGGL(k_ekf_win_psi<4>, dim3(4), dim3(256), 0, st, E, wd, nsteps);
-    } else if (wd.T == 8) {
-        hipLaunchKernelGGL(k_ekf_win_scan<8>, dim3(128 / WBW), dim3(256), 0, st, E, wd, nsteps);
-        hipLaunchKernelGGL(k_ekf_win_psi<8>, dim3(8), dim3(256), 0, st, E, wd, nsteps);
-    } else {
-        hipLaunchKernelGGL(k_ekf_win_scan<12>, dim3(192 / WBW), dim3(256), 0, st, E, wd, nsteps);
-        hipLaunchKernelGGL(k_ekf_win_psi<12>, dim3(12), dim3(256), 0, st, E, wd, nsteps);
-    }
 }
 void launch_ekf_win_flush(hipStream_t st, const EkfState& E, const WinDesc& wd) {
     const int SP = 16 * wd.T;
