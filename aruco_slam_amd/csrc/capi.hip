@@ -28,7 +28,6 @@ using namespace aslam;
 namespace {
 
 constexpr int kWinWidenFrames = 16;     // a window of at least this many frames is not widened to the next image size (64 -> 128 -> 192)
-constexpr int kWinLastPiece = 2;        // frames of a run's last chain piece (its scan and the flush are what the next window waits for)
 constexpr int kWinChainFrames = 8;      // frames per chain kernel of a window (its log is replayed meanwhile); <= kWinPieceMax
 
 enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
@@ -917,27 +916,36 @@ int finalize_pending(aslam_ctx* c) {
         launch_ekf_win_gather(sb, c->ekf, wd);                       // Y_0 of this window (behind the previous window's flush: same stream)
         // The pieces of the window, back to back on sa: launch i carries the chain of piece i, the replay of piece i - 1 and the Psi
         // product of piece i - 2 (ekf_window.hip: k_ekf_win_step), so nothing but the stream orders them; two more launches drain
-        // the replay.  What follows the window waits for that drain: the pieces shrink towards the end (.., 4, 2, 2 frames).
+        // the replay.  What follows the window waits for that drain: the pieces shrink towards the end (.., 4, 2, 1, 1 frames).
         struct Piece { WinDesc sub; int nsteps; };
         std::vector<Piece> pieces;
         {
-            int piece = 0, log0 = 0;
-            for (int k0 = 0, kn = 0; k0 < o.K; k0 += kn, piece++) {
-                const int left = o.K - k0;
-                if (left > 2 * kWinLastPiece) kn = std::min(c->win_piece, left - 2 * kWinLastPiece);
-                else if (left > kWinLastPiece) kn = left - kWinLastPiece;
-                else kn = left;
-                kn = std::min(kn, c->win_piece);
+            // piece sizes: the replay of piece i - 1 runs in the launch of piece i and takes about half as long per frame as the
+            // chain, so a piece may be at most twice as long as the one that follows it; from the window's end: 1, 1, 2, 4, 8, 8, ..
+            std::vector<int> sizes;
+            {
+                int left = o.K, nxt = 1, count = 0;
+                while (left > 0) {
+                    int kn = std::min(std::min(nxt, c->win_piece), left);
+                    sizes.push_back(kn);
+                    left -= kn;
+                    if (++count >= 2) nxt = std::min(2 * nxt, c->win_piece);       // 1, 1, 2, 4, ...
+                }
+                std::reverse(sizes.begin(), sizes.end());
+            }
+            int piece = 0, log0 = 0, k0 = 0;
+            for (int kn : sizes) {
                 Piece pc;
                 pc.sub = wd;
                 pc.sub.first_slot = o.frame + k0;
                 pc.sub.K = kn;
-                pc.sub.piece = piece;
+                pc.sub.piece = piece++;
                 pc.sub.log0 = log0;
                 pc.sub.last = k0 + kn == o.K ? 1 : 0;
                 pc.nsteps = 0;
                 for (int k = 0; k < kn; k++) pc.nsteps += 1 + c->h_win_frames[pc.sub.first_slot + k].m;
                 log0 += pc.nsteps;
+                k0 += kn;
                 pieces.push_back(pc);
             }
         }

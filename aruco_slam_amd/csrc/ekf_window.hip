@@ -36,6 +36,8 @@
 #include "ekf.h"
 #include "ekf_dev.h"
 #include <cmath>
+#include <cstdlib>
+#include <algorithm>
 
 namespace aslam {
 
@@ -794,13 +796,27 @@ __global__ __launch_bounds__(256) void k_ekf_win_next_fix(EkfState E, WinDesc pv
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------------
+// Every workgroup of a step launch asks for more than half of a CU's LDS (an unused dynamic allocation on top of the static one), so
+// that no second workgroup - a replay workgroup of the same launch, or anything else - is placed on the chain workgroup's CU and
+// competes with the prepare wave for issue slots and LDS bandwidth (ASLAM_WIN_SHARE_CU: off, for comparison).
+template <int T, class K> static void launch_step_kernel(K kernel, hipStream_t st, int nb, int nt, size_t static_lds, const EkfState& E, const SlamParams& sp,
+                                                const WinDesc& wd, const WinReplay& rs, const WinReplay& rq, const ObsRaw* obs, const double* enc) {
+    static const bool share = std::getenv("ASLAM_WIN_SHARE_CU") != nullptr;
+    const size_t dyn = share ? 0 : (size_t)84 * 1024 - std::min(static_lds, (size_t)20 * 1024);      // static + dynamic > 80 KB of the 160 KB
+    static bool attr_done = false;
+    if (!attr_done && dyn > 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(nb), dim3(nt), dyn, st, E, sp, wd, rs, rq, obs, enc);
+}
 void launch_ekf_win_step(hipStream_t st, const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* obs, const double* enc,
                          int s_piece, int s_log0, int s_nsteps, int q_piece, int q_log0, int q_nsteps) {
     const WinReplay rs{s_piece, s_log0, s_nsteps, wd.wpar}, rq{q_piece, q_log0, q_nsteps, wd.wpar};
     const int nb = 1 + 16 * wd.T / WBW + wd.T;
-    if (wd.T == 4) hipLaunchKernelGGL((k_ekf_win_step<4, 2>), dim3(nb), dim3(256), 0, st, E, sp, wd, rs, rq, obs, enc);
-    else if (wd.T == 8) hipLaunchKernelGGL((k_ekf_win_step<8, 2>), dim3(nb), dim3(320), 0, st, E, sp, wd, rs, rq, obs, enc);   // (3 + 3 + 2 rows on three workers: measured slower)
-    else hipLaunchKernelGGL((k_ekf_win_step<12, 2>), dim3(nb), dim3(448), 0, st, E, sp, wd, rs, rq, obs, enc);
+    if (wd.T == 4) launch_step_kernel<4>(k_ekf_win_step<4, 2>, st, nb, 256, sizeof(WinChainLds<4>), E, sp, wd, rs, rq, obs, enc);
+    else if (wd.T == 8) launch_step_kernel<8>(k_ekf_win_step<8, 2>, st, nb, 320, sizeof(WinChainLds<8>), E, sp, wd, rs, rq, obs, enc);   // (3 + 3 + 2 rows on three workers: measured slower)
+    else launch_step_kernel<12>(k_ekf_win_step<12, 2>, st, nb, 448, sizeof(WinChainLds<12>), E, sp, wd, rs, rq, obs, enc);
 }
 void launch_ekf_win_gather(hipStream_t st, const EkfState& E, const WinDesc& wd) {
     hipLaunchKernelGGL(k_ekf_win_gather, dim3((E.ld + 255) / 256, 16), dim3(256), 0, st, E, wd);       // y: rows of Y_0 in turn (one load in flight per thread otherwise)

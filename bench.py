@@ -610,7 +610,7 @@ def main():
         except Exception as e:
             extra["cfg5"] = {"error": repr(e)}
         try:
-            r3, run3 = run_config(mods, args, "cfg3", 3, 1, 100, True, 0, local_rank, 1, 16, want_gather=False)
+            r3, run3 = run_config(mods, args, "cfg3", 8, 2, 100, True, 0, local_rank, 1, 16, want_gather=False)    # (8 steps: the two-stage pipeline detection | EKF needs a few steps to show its steady rate)
             r3["unit"] = "frames/s"
             r3["cpu_baseline"] = cpu_baseline(np, synth, run3, "cfg3", True, (), 8.0)
             run3["ctx"].close()
