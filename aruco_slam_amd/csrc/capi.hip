@@ -34,7 +34,7 @@ enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_
               P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_EKF_MID64, P_EKF_WIN_CHAIN, P_EKF_WIN_SCAN, P_EKF_WIN_FLUSH, P_EKF_WIN_NEXT, P_COUNT };
 const char* kProfNames[P_COUNT] = {"k_threshold", "k_trace", "k_quads", "k_assemble", "k_identify", "k_pose",
                                    "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update_mfma", "k_ekf_mid", "k_ekf_apply",
-                                   "k_ekf_mid64", "k_ekf_win_chain", "k_ekf_win_scan", "k_ekf_win_flush", "k_ekf_win_next"};
+                                   "k_ekf_mid64", "k_ekf_win_step", "k_ekf_win_drain", "k_ekf_win_flush", "k_ekf_win_next"};
 
 struct ProfSpan { int id; hipEvent_t a, b; hipStream_t st; };
 

@@ -20,18 +20,22 @@
 // reference's pop order (ascending landmark index = ascending position in S), and may drop "stationary" observations
 // (aruco_slam.cpp:192-198: a no-op): a window ends only when a frame brings a landmark that does not fit into S, or a new one.
 //
-// Kernels (per window; a window's frames are cut into chain pieces of a few frames so that the replay runs beside the chain):
-//   k_ekf_win_chain   ONE workgroup walks the steps of a piece.  P lives in the f64 matrix-core accumulators of the worker waves for
-//                     the whole piece (wave w: RW tile rows of T 16 x 16 tiles); a step is one v_mfma_f64_16x16x4_f64 per tile
-//                     (depth 3 or 4).  A separate "prepare" wave (lane = column) runs one step AHEAD: the workers publish the six
-//                     rows (pose + landmark) of step j + 2 as they stand after step j, the prepare wave applies step j + 1's correction
-//                     to them itself from the operands it still holds (v_readlane, no LDS), forms c, S, S^-1, Kt and hands the
-//                     operands to the workers: one barrier per step.  It also logs -Kt, S^-1, ze and the Jacobian scalars;
-//                     further workgroups of the first piece copy Y_0 (rows S of Sigma) aside meanwhile.
-//   k_ekf_win_scan    SP / 16 workgroups replay the log, each on its own 16 columns of Lambda (all rows; in LDS) and its part
-//                     of psi, and log t and u;  k_ekf_win_psi adds the piece's t^T u to Psi on the matrix cores.
-//   k_ekf_win_thin    per 64 columns of Sigma: U = Psi Y_0 and Y_K = Lambda Y_0 (SP x 64, matrix cores), mu_R += Y_0^T psi;
+// Kernels (per window; a window's frames are cut into pieces of a few frames):
+//   k_ekf_win_step    one launch per piece, three roles by workgroup:
+//     chain   (workgroup 0) walks the steps of piece i.  P lives in the f64 matrix-core accumulators of the worker waves for the
+//             whole piece (wave w: RW tile rows of T 16 x 16 tiles); a step is one v_mfma_f64_16x16x4_f64 per tile (depth 3 or 4).
+//             A separate "prepare" wave (lane = column) runs one step AHEAD: the workers publish the six rows (pose + landmark) of
+//             step j + 2 as they stand after step j, the prepare wave applies step j + 1's correction to them itself from the
+//             operands of the previous step, forms c, S, S^-1, Kt and hands the operands to the workers: one barrier per step.  It
+//             also logs -Kt, S^-1, ze and the Jacobian scalars;
+//     replay  (SP / 8 workgroups) replays the log of piece i - 1, each on its own 8 columns of Lambda (all rows; in LDS) and its
+//             part of psi, and logs t and u;
+//     Psi     (T workgroups) adds the t^T u of piece i - 2 to Psi on the matrix cores.
+//             The three depend on each other only through the previous launch: the stream orders them, no events between pieces.
+//   k_ekf_win_gather  Y_0 = rows S of Sigma (second stream, behind the previous window's flush)
+//   k_ekf_win_thin    [Psi; Lambda] Y_0 as one tiled product (U = Psi Y_0, Y_K = Lambda Y_0), mu_R += Y_0^T psi;
 //   k_ekf_update_mfma (ekf.hip) Sigma -= Y_0^T U: the ONE pass over Sigma per window;  k_ekf_win_fix writes rows / columns S and P_K.
+//   k_ekf_win_next_*  the next window's P and mu_S from this window's small results, before its flush has run.
 #include "common.h"
 #include "ekf.h"
 #include "ekf_dev.h"

@@ -345,7 +345,7 @@ def test_windowed_and_per_frame_ekf_agree_on_the_full_pipeline():
         c.sync()
         ctxs.append(c)
     a, b = ctxs
-    assert a.profile_get()["k_ekf_win_chain"][0] > 0 and b.profile_get()["k_ekf_win_chain"][0] == 0
+    assert a.profile_get()["k_ekf_win_step"][0] > 0 and b.profile_get()["k_ekf_win_step"][0] == 0
     mu_a, S_a = a.get_state(); mu_b, S_b = b.get_state()
     assert mu_a.shape == mu_b.shape and mu_a.size > 3 + 3 * 20
     assert np.allclose(mu_a, mu_b, rtol=1e-10, atol=1e-12) and np.abs(S_a - S_b).max() <= 1e-10 * np.abs(S_a).max()
