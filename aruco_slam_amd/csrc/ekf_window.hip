@@ -133,11 +133,11 @@ template <int T> struct WinChainLds {
     int sOff[kWinPieceMax + 1];
     unsigned char sPos[NSMAX], sIdx[NSMAX], sFrm[NSMAX];   // per step: landmark position (255 = predict), correction index, frame
 };
-template <int T, int RW, int NPW>
+template <int T, int RW>
 __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const WinDesc& wd, const ObsRaw* __restrict__ obs,
                                const double* __restrict__ enc, unsigned char* smem) {
     constexpr int SP = 16 * T, SPP = SP + 16, NC = SP / 64;       // SPP: operand rows lk and lk + 1 fall on opposite halves of the bank row
-    constexpr int NWK = (T + RW - 1) / RW, NT = (NWK + NPW) * 64;
+    constexpr int NWK = (T + RW - 1) / RW, NT = (NWK + 1) * 64;
     WinChainLds<T>& L = *reinterpret_cast<WinChainLds<T>*>(smem);
     auto& sA = L.sA; auto& sB = L.sB; auto& sPub = L.sPub; auto& sMu = L.sMu; auto& sS = L.sS; auto& sOff = L.sOff;
     auto& sPos = L.sPos; auto& sIdx = L.sIdx; auto& sFrm = L.sFrm;
@@ -231,7 +231,6 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
                 }
             }
             WSTAMP(1);
-            if (NPW > 1) ASLAM_LDS_BARRIER();                       // (the prepare waves exchange their columns in the middle of the phase)
             ASLAM_LDS_BARRIER();
         }
 #ifdef ASLAM_WIN_STAMPS
@@ -249,24 +248,20 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
         return;
     }
 
-    // ============================== prepare wave(s): lane = column; NPW waves of NCL = NC / NPW chunks of 64 ==============================
+    // ======================================= prepare wave: lane = column (NC chunks of 64) =======================================
     // What a step needs from another column (the previous step's A operand at the six row indices, c at the six special columns)
     // is wave-uniform and is read back from LDS as a broadcast - the operands live there anyway (measured: cheaper than v_readlane
-    // plus chunk selection).  With more than one prepare wave (128-wide: one per 64 columns) every wave runs the same
-    // step on its own columns; what they need from each other (c at the special columns; mu_S and P22 for a predict) crosses through
-    // LDS at one extra workgroup barrier in the middle of the phase - the scalar part (S, its inverse, the records) is redundant.
+    // plus chunk selection).
 #ifndef ASLAM_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);                                  // the critical path of the kernel: wins the issue slot over the worker wave it shares a SIMD with
 #endif
-    constexpr int NCL = NC / NPW;
-    const int pw = wave - NWK, c0 = pw * NCL;                      // this wave's first chunk
     const double kl = sp.kl, kr = sp.kr, inv2b = 1.0 / (2 * sp.b), invb = 1 / sp.b, Qk = sp.Q_k;
     double* const logbase = E.d_win_log + (size_t)wd.log0 * win_log_stride(T);
     double* const muimg = E.d_win_small + wsm_MU(E.win_sp_max, wd.wpar);
-    double mu[NCL], pB[4][NCL];
+    double mu[NC], pB[4][NC];
 #pragma unroll
-    for (int c = 0; c < NCL; c++) {
-        const int col = lane + 64 * (c0 + c);
+    for (int c = 0; c < NC; c++) {
+        const int col = lane + 64 * c;
         // mu_S travels between the pieces of a window in its image; only the window's last piece puts it back into the state
         mu[c] = col >= s ? 0.0 : (wd.piece != 0 || wd.from_image != 0) ? muimg[col] : E.d_mu[sS[col]];
 #pragma unroll
@@ -290,20 +285,16 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
     for (int j = -1; j < NS; j++) {
         const int n = j + 1;                                       // the step prepared in this phase
         WSTAMP(0);
-        const bool live = n < NS;
-        const int nb = n & 1, pb = j & 1;
-        const int pos = live ? sPos[n] : 255;
-        const bool is_predict = pos == 255;
-        const int lrow = is_predict ? 0 : 3 + 3 * pos;             // first landmark row (a predict has none: copies of the pose rows)
-        double r[6][NCL], cc[3][NCL];
-        double ze0 = 0, ze1 = 0, ze2 = 0, R0 = 0, R1 = 0, R2 = 0, g02 = 0, g12 = 0;
-        int a = 0;
-        // ------------------------------- first half: this wave's columns of the six rows, corrected; c -------------------------------
-        if (live) {
+        if (n < NS) {
+            const int nb = n & 1, pb = j & 1;
+            const int pos = sPos[n];
+            const bool is_predict = pos == 255;
+            const int lrow = is_predict ? 0 : 3 + 3 * pos;         // first landmark row (a predict has none: copies of the pose rows)
+            double r[6][NC];
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
-                for (int c = 0; c < NCL; c++) r[i][c] = sPub[nb][i][lane + 64 * (c0 + c)];
+                for (int c = 0; c < NC; c++) r[i][c] = sPub[nb][i][lane + 64 * c];
             if (j >= 0) {
                 // step j's correction of these rows: P[R][col] += sum_k Aop_j[k][R] Bop_j[k][col]
 #pragma unroll
@@ -312,43 +303,16 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
                     const double f0 = sA[pb][kk][0], f1 = sA[pb][kk][1], f2 = sA[pb][kk][2];      // (LDS broadcast reads: measured faster than v_readlane)
                     const double f3 = sA[pb][kk][lrow], f4 = sA[pb][kk][lrow + 1], f5 = sA[pb][kk][lrow + 2];
 #pragma unroll
-                    for (int c = 0; c < NCL; c++) {
+                    for (int c = 0; c < NC; c++) {
                         r[0][c] = fma(f0, pB[kk][c], r[0][c]); r[1][c] = fma(f1, pB[kk][c], r[1][c]); r[2][c] = fma(f2, pB[kk][c], r[2][c]);
                         r[3][c] = fma(f3, pB[kk][c], r[3][c]); r[4][c] = fma(f4, pB[kk][c], r[4][c]); r[5][c] = fma(f5, pB[kk][c], r[5][c]);
                     }
                 }
             }
             WSTAMP(1);
-            if (is_predict) {
-                // the mean as the previous frame left it, for every prepare wave (pose: chunk 0; landmark means: anywhere); P22
-#pragma unroll
-                for (int c = 0; c < NCL; c++) sMu[lane + 64 * (c0 + c)] = mu[c];
-                if (c0 == 0 && lane == 2) sMu[SP + 8] = r[2][0];     // P22 = (row 2, column 2), in the padding of the scratch row
-            } else {
-                // ---- correction a of the frame: c = H P ----
-                a = sIdx[n];
-                ze0 = ASLAM_WAVE_BCAST(rze0, a); ze1 = ASLAM_WAVE_BCAST(rze1, a); ze2 = ASLAM_WAVE_BCAST(rze2, a);
-                R0 = ASLAM_WAVE_BCAST(rR0, a); R1 = ASLAM_WAVE_BCAST(rR1, a); R2 = ASLAM_WAVE_BCAST(rR2, a);
-                g02 = ASLAM_WAVE_BCAST(rg02, a); g12 = ASLAM_WAVE_BCAST(rg12, a);
-                // Gxm = [ -c -s g02  c  s 0 ;  s -c g12 -s  c 0 ;  0 0 -1  0 0 1 ]   (aruco_slam.cpp:140-143)
-#pragma unroll
-                for (int c = 0; c < NCL; c++) {
-                    const int col = lane + 64 * (c0 + c);
-                    cc[0][c] = (-cth * r[0][c] - sth * r[1][c] + g02 * r[2][c]) + (cth * r[3][c] + sth * r[4][c]);
-                    cc[1][c] = (sth * r[0][c] - cth * r[1][c] + g12 * r[2][c]) + (-sth * r[3][c] + cth * r[4][c]);
-                    cc[2][c] = r[5][c] - r[2][c];
-                    sB[nb][0][col] = cc[0][c]; sB[nb][1][col] = cc[1][c]; sB[nb][2][col] = cc[2][c];   // (the B operand, in place)
-                }
-            }
-        }
-        if (NPW > 1) ASLAM_LDS_BARRIER();                          // the other prepare waves' columns (the workers pass through too)
-        else __builtin_amdgcn_wave_barrier();
-        WSTAMP(3);
-        // ------------------------------- second half: the scalar part, then this wave's columns of the operands -------------------------------
-        if (live) {
             double* log = logbase + (size_t)n * win_log_stride(T);
             double* hdr = log + 3 * SP;
-            double A[4][NCL], B[4][NCL];
+            double A[4][NC], B[4][NC];
             if (is_predict) {
 #ifdef ASLAM_WIN_STAMPS
                 n_pred++;
@@ -360,6 +324,9 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
                 const double delta_sl = kl * (e_dt * e_wl), delta_sr = kr * (e_dt * e_wr);
                 const double delta_theta = (delta_sr - delta_sl) * inv2b;
                 const double delta_s = 0.5 * (delta_sr + delta_sl);
+#pragma unroll
+                for (int c = 0; c < NC; c++) sMu[lane + 64 * c] = mu[c];
+                __builtin_amdgcn_wave_barrier();
                 const double m0 = sMu[0], m1 = sMu[1], m2 = sMu[2];
                 double th = m2 + delta_theta;
                 wrap1(th);
@@ -371,10 +338,10 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
                 const double ua = -delta_s * sm, ub = delta_s * cm;                 // H3 = I + [ua ub 0]^T e2^T
                 const double f = 0.5 * kl * e_dt;                                    // kl for BOTH wheels (quirk Q7)
                 const double su0 = Qk * fabs(e_wl), su1 = Qk * fabs(e_wr);
-                const double P22 = sMu[SP + 8];
+                const double P22 = ASLAM_WAVE_BCAST(r[2][0], 2);
 #pragma unroll
-                for (int c = 0; c < NCL; c++) {
-                    const int col = lane + 64 * (c0 + c);
+                for (int c = 0; c < NC; c++) {
+                    const int col = lane + 64 * c;
                     const double u = col == 0 ? ua : col == 1 ? ub : 0.0;
                     const double w0 = col == 0 ? f * cm : col == 1 ? f * sm : col == 2 ? f * invb : 0.0;        // wkh column 0
                     const double w1 = col == 0 ? f * cm : col == 1 ? f * sm : col == 2 ? f * -invb : 0.0;       // wkh column 1
@@ -386,11 +353,9 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
                 }
                 if (nb) dirty1 = true; else dirty0 = true;
                 const double np0 = m0 + delta_s * cm, np1 = m1 + delta_s * sm;
-                if (c0 == 0) {
-                    if (lane == 0) mu[0] = np0;
-                    if (lane == 1) mu[0] = np1;
-                    if (lane == 2) mu[0] = th;
-                }
+                if (lane == 0) mu[0] = np0;
+                if (lane == 1) mu[0] = np1;
+                if (lane == 2) mu[0] = th;
                 // ---- the frame's records at the frozen mean (pose just predicted, landmarks as the previous frame left them) ----
                 if (lane < fm) {
                     const int q = 3 + 3 * sPos[sOff[k] + 1 + lane];
@@ -405,12 +370,13 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
                     rg02 = -gdx * sth + gdy * cth; rg12 = -gdx * cth - gdy * sth;
                     rR0 = nObs.r[0]; rR1 = nObs.r[1]; rR2 = nObs.r[2];
                 }
+                __builtin_amdgcn_wave_barrier();
                 const WinFrame& fr = frames[slot];
-                if (pw == 0 && lane == 0 && slot < E.max_slots) {
+                if (lane == 0 && slot < E.max_slots) {
                     int* st = E.d_slot_stat + 4 * slot;
                     st[0] = fr.n_markers; st[1] = 0; st[2] = fm; st[3] = fr.npop - fm;
                 }
-                if (pw == 0 && wd.last && k == wd.K - 1) {
+                if (wd.last && k == wd.K - 1) {
                     // what the window's last frame leaves behind for whatever follows: pop list, last_observed_marker_ (aruco_slam.cpp:202, 263)
                     const int npop = fr.npop;
                     if (lane < npop) {
@@ -437,10 +403,25 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
                     e_wl = e[0]; e_wr = e[1]; e_dt = e[2];
                 }
                 // header of the logged step: type 0, D's two entries, the frame's cos / sin (the corrections of the frame use them)
-                if (pw == 0 && lane == 0) { hdr[WH_TYPE] = 0.0; hdr[WH_POS] = -1.0; hdr[WH_A] = ua; hdr[WH_B] = ub; hdr[WH_C] = cth; hdr[WH_S] = sth; }
+                if (lane == 0) { hdr[WH_TYPE] = 0.0; hdr[WH_POS] = -1.0; hdr[WH_A] = ua; hdr[WH_B] = ub; hdr[WH_C] = cth; hdr[WH_S] = sth; }
                 WSTAMP(2);
             } else {
-                // ---- S = c H^T + R from c at the six special columns, Kt = S^-1 c ----
+                // ---- correction a of the frame: c = H P, S = c H^T + R, Kt = S^-1 c ----
+                const int a = sIdx[n];
+                const double ze0 = ASLAM_WAVE_BCAST(rze0, a), ze1 = ASLAM_WAVE_BCAST(rze1, a), ze2 = ASLAM_WAVE_BCAST(rze2, a);
+                const double R0 = ASLAM_WAVE_BCAST(rR0, a), R1 = ASLAM_WAVE_BCAST(rR1, a), R2 = ASLAM_WAVE_BCAST(rR2, a);
+                const double g02 = ASLAM_WAVE_BCAST(rg02, a), g12 = ASLAM_WAVE_BCAST(rg12, a);
+                // Gxm = [ -c -s g02  c  s 0 ;  s -c g12 -s  c 0 ;  0 0 -1  0 0 1 ]   (aruco_slam.cpp:140-143)
+                double cc[3][NC];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    cc[0][c] = (-cth * r[0][c] - sth * r[1][c] + g02 * r[2][c]) + (cth * r[3][c] + sth * r[4][c]);
+                    cc[1][c] = (sth * r[0][c] - cth * r[1][c] + g12 * r[2][c]) + (-sth * r[3][c] + cth * r[4][c]);
+                    cc[2][c] = r[5][c] - r[2][c];
+                    sB[nb][0][lane + 64 * c] = cc[0][c]; sB[nb][1][lane + 64 * c] = cc[1][c]; sB[nb][2][lane + 64 * c] = cc[2][c];   // (the B operand, in place)
+                }
+                __builtin_amdgcn_wave_barrier();
+                WSTAMP(3);
                 double Sm[9], Si[9];
 #pragma unroll
                 for (int kk = 0; kk < 3; kk++) {
@@ -454,7 +435,7 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
                 inv3_fast(Sm, Si);
                 WSTAMP(4);
 #pragma unroll
-                for (int c = 0; c < NCL; c++) {
+                for (int c = 0; c < NC; c++) {
                     // K = (P H^T) S^-1, (P H^T) = c^T:  Kt[k][col] = sum_k' c[k'][col] Si[k'][k];  the A operand is -Kt
                     const double k0 = cc[0][c] * Si[0] + cc[1][c] * Si[3] + cc[2][c] * Si[6];
                     const double k1 = cc[0][c] * Si[1] + cc[1][c] * Si[4] + cc[2][c] * Si[7];
@@ -465,24 +446,22 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
                 }
                 if (nb ? dirty1 : dirty0) {                         // the buffer last held a predict's fourth depth row
 #pragma unroll
-                    for (int c = 0; c < NCL; c++) { sA[nb][3][lane + 64 * (c0 + c)] = 0.0; sB[nb][3][lane + 64 * (c0 + c)] = 0.0; }
+                    for (int c = 0; c < NC; c++) { sA[nb][3][lane + 64 * c] = 0.0; sB[nb][3][lane + 64 * c] = 0.0; }
                     if (nb) dirty1 = false; else dirty0 = false;
                 }
                 // header of the logged step, stored by the lanes that hold the values
-                if (pw == 0) {
-                    if (lane == 0) {
-                        hdr[WH_TYPE] = 1.0; hdr[WH_POS] = (double)pos;
+                if (lane == 0) {
+                    hdr[WH_TYPE] = 1.0; hdr[WH_POS] = (double)pos;
 #pragma unroll
-                        for (int q = 0; q < 9; q++) hdr[WH_SI + q] = Si[q];
-                    }
-                    if (lane == a) { hdr[WH_ZE] = rze0; hdr[WH_ZE + 1] = rze1; hdr[WH_ZE + 2] = rze2; hdr[WH_G02] = rg02; hdr[WH_G12] = rg12; }
+                    for (int q = 0; q < 9; q++) hdr[WH_SI + q] = Si[q];
                 }
+                if (lane == a) { hdr[WH_ZE] = rze0; hdr[WH_ZE + 1] = rze1; hdr[WH_ZE + 2] = rze2; hdr[WH_G02] = rg02; hdr[WH_G12] = rg12; }
                 WSTAMP(5);
             }
             // operands to the workers, the log, and this wave's own copy
 #pragma unroll
-            for (int c = 0; c < NCL; c++) {
-                const int col = lane + 64 * (c0 + c);
+            for (int c = 0; c < NC; c++) {
+                const int col = lane + 64 * c;
                 sA[nb][0][col] = A[0][c]; sA[nb][1][col] = A[1][c]; sA[nb][2][col] = A[2][c];
                 if (is_predict) { sB[nb][0][col] = B[0][c]; sB[nb][1][col] = B[1][c]; sB[nb][2][col] = B[2][c]; }
                 log[col] = A[0][c]; log[SP + col] = A[1][c]; log[2 * SP + col] = A[2][c];
@@ -495,17 +474,17 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
         ASLAM_LDS_BARRIER();
     }
 #ifdef ASLAM_WIN_STAMPS
-    if (lane == 0 && pw == 0 && wd.piece == 1) {
+    if (lane == 0 && wd.piece == 1) {
         const int nc = NS - n_pred;
-        printf("prepare T %d steps %d (%d predict): barrier %lld | rows+correct %lld | predict path %lld per predict | mid %lld S+inv %lld Kt+hdr %lld per correction | operands+log %lld per step\n",
-               T, NS, n_pred, stamp_acc[0] / (NS + 1), stamp_acc[1] / NS, stamp_acc[2] / (n_pred ? n_pred : 1), stamp_acc[3] / (NS + 1), stamp_acc[4] / (nc ? nc : 1),
+        printf("prepare T %d steps %d (%d predict): barrier %lld | rows+correct %lld | predict path %lld per predict | c %lld S+inv %lld Kt+hdr %lld per correction | operands+log %lld per step\n",
+               T, NS, n_pred, stamp_acc[0] / (NS + 1), stamp_acc[1] / NS, stamp_acc[2] / (n_pred ? n_pred : 1), stamp_acc[3] / (nc ? nc : 1), stamp_acc[4] / (nc ? nc : 1),
                stamp_acc[5] / (nc ? nc : 1), stamp_acc[6] / NS);
     }
 #endif
     // ---- mu_S for the next piece; back into the state at the window's end ----
 #pragma unroll
-    for (int c = 0; c < NCL; c++) {
-        const int col = lane + 64 * (c0 + c);
+    for (int c = 0; c < NC; c++) {
+        const int col = lane + 64 * c;
         if (col < s) { muimg[col] = mu[c]; if (wd.last) E.d_mu[sS[col]] = mu[c]; }
     }
 }
@@ -676,14 +655,14 @@ __device__ void win_psi_role(const EkfState& E, const WinReplay& wd, int tr) {
 // product of piece i - 2 (the last T workgroups).  The three depend on each other only through the PREVIOUS launch (the log of
 // piece i - 1 is complete when this launch starts: same stream), so no events are needed between the pieces of a window and the
 // replay is hidden behind the chain: with one event per piece the EKF alone ran 14 % slower (cfg2).
-template <int T, int RW, int NPW>
-__global__ __launch_bounds__(((T + RW - 1) / RW + NPW) * 64 > 256 ? ((T + RW - 1) / RW + NPW) * 64 : 256)
+template <int T, int RW>
+__global__ __launch_bounds__(((T + RW - 1) / RW + 1) * 64 > 256 ? ((T + RW - 1) / RW + 1) * 64 : 256)
 void k_ekf_win_step(EkfState E, SlamParams sp, WinDesc wd, WinReplay rs, WinReplay rq, const ObsRaw* __restrict__ obs, const double* __restrict__ enc) {
     constexpr size_t kLds = sizeof(WinChainLds<T>) > sizeof(WinScanLds<T>) ? sizeof(WinChainLds<T>) : sizeof(WinScanLds<T>);
     __shared__ __align__(16) unsigned char smem[kLds];
     constexpr int NSCAN = 16 * T / WBW;
     const int bx = blockIdx.x;
-    if (bx == 0) { if (wd.K > 0) win_chain_role<T, RW, NPW>(E, sp, wd, obs, enc, smem); }
+    if (bx == 0) { if (wd.K > 0) win_chain_role<T, RW>(E, sp, wd, obs, enc, smem); }
     else if (bx <= NSCAN) { if (rs.nsteps > 0) win_scan_role<T>(E, rs, bx - 1, smem); }
     else if (rq.nsteps > 0) win_psi_role<T>(E, rq, bx - 1 - NSCAN);
 }
@@ -839,9 +818,9 @@ void launch_ekf_win_step(hipStream_t st, const EkfState& E, const SlamParams& sp
                          int s_piece, int s_log0, int s_nsteps, int q_piece, int q_log0, int q_nsteps) {
     const WinReplay rs{s_piece, s_log0, s_nsteps, wd.wpar}, rq{q_piece, q_log0, q_nsteps, wd.wpar};
     const int nb = 1 + 16 * wd.T / WBW + wd.T;
-    if (wd.T == 4) launch_step_kernel<4>(k_ekf_win_step<4, 2, 1>, st, nb, 256, sizeof(WinChainLds<4>), E, sp, wd, rs, rq, obs, enc);
-    else if (wd.T == 8) launch_step_kernel<8>(k_ekf_win_step<8, 2, 2>, st, nb, 384, sizeof(WinChainLds<8>), E, sp, wd, rs, rq, obs, enc);   // (3 + 3 + 2 rows on three workers: measured slower)
-    else launch_step_kernel<12>(k_ekf_win_step<12, 2, 1>, st, nb, 448, sizeof(WinChainLds<12>), E, sp, wd, rs, rq, obs, enc);
+    if (wd.T == 4) launch_step_kernel<4>(k_ekf_win_step<4, 2>, st, nb, 256, sizeof(WinChainLds<4>), E, sp, wd, rs, rq, obs, enc);
+    else if (wd.T == 8) launch_step_kernel<8>(k_ekf_win_step<8, 2>, st, nb, 320, sizeof(WinChainLds<8>), E, sp, wd, rs, rq, obs, enc);   // (3 + 3 + 2 rows on three workers: measured slower)
+    else launch_step_kernel<12>(k_ekf_win_step<12, 2>, st, nb, 448, sizeof(WinChainLds<12>), E, sp, wd, rs, rq, obs, enc);
 }
 void launch_ekf_win_gather(hipStream_t st, const EkfState& E, const WinDesc& wd) {
     hipLaunchKernelGGL(k_ekf_win_gather, dim3((E.ld + 255) / 256, 16), dim3(256), 0, st, E, wd);       // y: rows of Y_0 in turn (one load in flight per thread otherwise)
