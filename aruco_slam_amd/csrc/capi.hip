@@ -77,9 +77,11 @@ struct aslam_ctx {
     unsigned* d_ncontours = nullptr;
     unsigned* d_points = nullptr;          // per frame: cap_points packed (x, y)
     unsigned* d_npoints = nullptr;
-    CkptRec* d_ckpt = nullptr;             // per frame: cap_ckpt walk checkpoints of the kept contours
-    unsigned* d_nckpt = nullptr;
-    unsigned* d_lane_ckpt = nullptr;       // k_trace: checkpoints of the walk each lane has in progress
+    unsigned* d_nodeplane = nullptr;       // per frame and scale: index of a pixel's first border node (tiled like the mask planes; only entries of pixels that carry nodes are ever written or read)
+    NodeRec* d_nodes = nullptr;            // per frame: cap_starts segments (k_seg)
+    WriteRec* d_wlist = nullptr;           // per frame: cap_write write tickets (k_link)
+    unsigned* d_nwrite = nullptr;
+    unsigned* d_link_todo = nullptr;       // per frame: left to k_link_serial
     unsigned* d_pre_write = nullptr;
     unsigned* d_pre_trace = nullptr;       // ticket ranges of the work-queue kernels
     unsigned* d_pre_quads = nullptr;
@@ -282,8 +284,7 @@ int configure_frames(aslam_ctx* c, int rows, int cols, int channels) {
     g.cap_starts = c->init.cap_starts_per_frame;
     g.cap_contours = c->init.cap_contours_per_frame;
     g.cap_points = c->init.cap_points_per_frame;
-    g.cap_ckpt = g.cap_points / kCkptStride + g.cap_contours;
-    g.ckpt_per_walk = g.max_perim / kCkptStride + 2;      // <= the per-lane allocation sized from max_rows / max_cols
+    g.cap_write = g.cap_points / kWriteChunk + g.cap_contours;
     return ASLAM_OK;
 }
 
@@ -338,7 +339,7 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
         HIP_TRY(c, hipMemsetAsync(c->d_nstarts + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_ncontours + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_npoints + f0, 0, sizeof(unsigned) * nf, st));
-        HIP_TRY(c, hipMemsetAsync(c->d_nckpt + f0, 0, sizeof(unsigned) * nf, st));
+        HIP_TRY(c, hipMemsetAsync(c->d_nwrite + f0, 0, sizeof(unsigned) * nf, st));
         HIP_TRY(c, hipMemsetAsync(c->d_ncand + f0, 0, sizeof(unsigned) * nf, st));
         const uint8_t* in = c->d_in + (size_t)f0 * c->in_frame_bytes;
         uint8_t* nbr = c->d_nbr + (size_t)f0 * kScales * nbr_plane_bytes(g.rows, g.pitch);
@@ -348,15 +349,19 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
         unsigned* points = c->d_points + (size_t)f0 * g.cap_points;
         prof_begin(c, P_THRESH, st);
         launch_threshold(st, in, c->channels, c->in_frame_bytes, (size_t)g.cols * c->channels, nf,
-                         alias_gray ? nullptr : c->d_gray + (size_t)f0 * frame_px, nbr, g, starts, c->d_nstarts + f0, c->d_ctr);
+                         alias_gray ? nullptr : c->d_gray + (size_t)f0 * frame_px, nbr, g, starts, c->d_nstarts + f0,
+                         c->d_nodeplane + (size_t)f0 * kScales * nbr_plane_bytes(g.rows, g.pitch), c->d_ctr);
         prof_end(c);
         prof_begin(c, P_TRACE, st);
         launch_prefix(st, nf, c->d_nstarts + f0, g.cap_starts, 1u, c->d_pre_trace);
-        CkptRec* ckpt = c->d_ckpt + (size_t)f0 * g.cap_ckpt;
-        launch_trace(st, c->nwaves, nbr, g, nf, starts, c->d_pre_trace, c->d_ctr, contours, c->d_ncontours + f0,
-                     c->d_npoints + f0, ckpt, c->d_nckpt + f0, c->d_lane_ckpt);
-        launch_prefix(st, nf, c->d_nckpt + f0, g.cap_ckpt, 1u, c->d_pre_write);
-        launch_trace_write(st, std::max(64, c->nwaves / 4), nbr, g, nf, c->d_pre_write, c->d_ctr, contours, ckpt, points);
+        NodeRec* nodes = c->d_nodes + (size_t)f0 * g.cap_starts;
+        WriteRec* wlist = c->d_wlist + (size_t)f0 * g.cap_write;
+        launch_seg(st, c->nwaves, nbr, g, nf, starts, c->d_nstarts + f0, c->d_nodeplane + (size_t)f0 * kScales * nbr_plane_bytes(g.rows, g.pitch),
+                   c->d_pre_trace, c->d_ctr, nodes);
+        launch_link(st, g, nf, c->d_nstarts + f0, c->d_ctr, nodes, c->d_link_todo + f0, contours, c->d_ncontours + f0, c->d_npoints + f0, wlist,
+                    c->d_nwrite + f0);
+        launch_prefix(st, nf, c->d_nwrite + f0, g.cap_write, 1u, c->d_pre_write);
+        launch_trace_write(st, std::max(64, c->nwaves / 4), nbr, g, nf, c->d_pre_write, c->d_ctr, contours, wlist, points);
         prof_end(c);
         prof_begin(c, P_QUADS, st);
         launch_prefix(st, nf, c->d_ncontours + f0, g.cap_contours, 1u, c->d_pre_quads);
@@ -555,11 +560,13 @@ int aslam_create(const aslam_init* init, aslam_ctx** out) {
     ok = ok && dalloc(&c->d_ncontours, B) == hipSuccess;
     ok = ok && dalloc(&c->d_points, (size_t)c->init.cap_points_per_frame * B) == hipSuccess;
     ok = ok && dalloc(&c->d_npoints, B) == hipSuccess;
-    ok = ok && dalloc(&c->d_ckpt, ((size_t)c->init.cap_points_per_frame / kCkptStride + c->init.cap_contours_per_frame) * B) == hipSuccess;
-    ok = ok && dalloc(&c->d_nckpt, B) == hipSuccess;
-    ok = ok && dalloc(&c->d_lane_ckpt, (size_t)c->nwaves * 64 * ((size_t)(4.0 * std::max(init->max_rows, init->max_cols)) / kCkptStride + 2)) == hipSuccess;
-    ok = ok && dalloc(&c->d_refine_mask, 15 * 15) == hipSuccess;
+    ok = ok && dalloc(&c->d_nodeplane, (size_t)kScales * nbr_plane_bytes(init->max_rows, (int)pitch) * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_nodes, (size_t)c->init.cap_starts_per_frame * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_wlist, ((size_t)c->init.cap_points_per_frame / kWriteChunk + c->init.cap_contours_per_frame) * B) == hipSuccess;
+    ok = ok && dalloc(&c->d_nwrite, B) == hipSuccess;
+    ok = ok && dalloc(&c->d_link_todo, B) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_write, (size_t)max_frames_per_call() + 1) == hipSuccess;
+    ok = ok && dalloc(&c->d_refine_mask, 15 * 15) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_trace, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_pre_quads, (size_t)max_frames_per_call() + 1) == hipSuccess;
     ok = ok && dalloc(&c->d_cands, (size_t)kCandMax * B) == hipSuccess;
@@ -609,7 +616,7 @@ void aslam_destroy(aslam_ctx* c) {
     prof_collect(c);
     hipFree(c->d_in); hipFree(c->d_gray); hipFree(c->d_nbr); hipFree(c->d_starts); hipFree(c->d_ctr);
     hipFree(c->d_refine_mask);
-    hipFree(c->d_ckpt); hipFree(c->d_nckpt); hipFree(c->d_lane_ckpt); hipFree(c->d_pre_write);
+    hipFree(c->d_nodeplane); hipFree(c->d_nodes); hipFree(c->d_wlist); hipFree(c->d_nwrite); hipFree(c->d_link_todo); hipFree(c->d_pre_write);
     hipFree(c->d_nstarts); hipFree(c->d_ncontours); hipFree(c->d_npoints); hipFree(c->d_pre_trace); hipFree(c->d_pre_quads);
     hipFree(c->d_contours); hipFree(c->d_points); hipFree(c->d_cands); hipFree(c->d_ncand); hipFree(c->d_finals);
     hipFree(c->d_nfinal); hipFree(c->d_work); hipFree(c->d_dict); hipFree(c->d_markers); hipFree(c->d_nmarkers);
@@ -1163,9 +1170,9 @@ int aslam_set_detector_params(aslam_ctx* c, const aslam_detector_params* p) {
     if (p->doCornerRefinement && (p->cornerRefinementWinSize < 1 || p->cornerRefinementWinSize > 7 || p->cornerRefinementMaxIterations < 1 ||
                                   !(p->cornerRefinementMinAccuracy > 0)))
         return fail(c, ASLAM_E_INVALID, "corner refinement: window 1..7, at least one iteration, positive accuracy");
-    if (!(p->maxMarkerPerimeterRate > 0 && p->maxMarkerPerimeterRate <= 4.0) || !(p->minMarkerPerimeterRate > 0) ||
-        p->minMarkerPerimeterRate > p->maxMarkerPerimeterRate)
-        return fail(c, ASLAM_E_INVALID, "0 < minMarkerPerimeterRate <= maxMarkerPerimeterRate <= 4");
+    if (!(p->maxMarkerPerimeterRate > 0) || !(p->minMarkerPerimeterRate > 0) || p->minMarkerPerimeterRate > p->maxMarkerPerimeterRate ||
+        p->maxMarkerPerimeterRate * std::max(c->init.max_rows, c->init.max_cols) > 65534.0)
+        return fail(c, ASLAM_E_INVALID, "0 < minMarkerPerimeterRate <= maxMarkerPerimeterRate, and the longest kept border (rate x larger frame side) <= 65534 points");
     if (!(p->polygonalApproxAccuracyRate > 0) || p->minCornerDistanceRate < 0 || p->minMarkerDistanceRate < 0 || p->minDistanceToBorder < 0 ||
         p->adaptiveThreshConstant < 0 || p->adaptiveThreshConstant > 255 || p->perspectiveRemoveIgnoredMarginPerCell < 0 ||
         p->perspectiveRemoveIgnoredMarginPerCell >= 0.5 || p->maxErroneousBitsInBorderRate < 0 || p->errorCorrectionRate < 0 || p->minOtsuStdDev < 0)

@@ -13,6 +13,11 @@
 #define ASLAM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// The dynamic LDS allocation of a launch (the CPU emulation gives every workgroup a fixed array).
+#ifndef ASLAM_DYN_LDS
+#define ASLAM_DYN_LDS(name) extern __shared__ __align__(16) unsigned char name[]
+#endif
+
 namespace aslam {
 
 constexpr int kScales = 3;        // adaptive-threshold windows 3, 13, 23 (DetectorParameters defaults)
@@ -45,26 +50,48 @@ struct DetectCfg {
     int max_corr;                     // int(maxCorrectionBits * errorCorrectionRate)
     int n_dict;                       // markers in the dictionary
     double min_otsu_std;              // 5.0
-    unsigned cap_starts, cap_contours, cap_points, cap_ckpt;   // per frame
-    int ckpt_per_walk;                // checkpoints one border walk can leave: max_perim / kCkptStride + 2
+    unsigned cap_starts, cap_contours, cap_points, cap_write;   // per frame (cap_starts: border nodes = start candidates + cut states; cap_write: write tickets)
 };
 
 struct Counters {                 // per-call scalars (work-queue heads, overflow mask); list sizes live in per-frame arrays
-    unsigned q_trace, q_quads, n_ident, q_ident, q_write, overflow, pad[2];
+    unsigned q_trace, q_quads, n_ident, q_ident, q_write, q_link, overflow, pad;
 };
-constexpr int kCounterHeads = 5;  // leading words reset before every detection call (the overflow mask is sticky)
+constexpr int kCounterHeads = 6;  // leading words reset before every detection call (the overflow mask is sticky)
 
 struct ContourRec {
     unsigned frame, scale, key, n, off;
     short sx, sy;                 // the start state the sequential scan would have used (point 0 of the contour)
     int s0;
-    unsigned ck_off;              // first of its ceil(n / kCkptStride) checkpoints in the frame's checkpoint list
-    int kpos;                     // step of the closing walk at which it stood on (sx, sy, s0): point i = walk step kpos + i (mod n)
+    unsigned pad[2];
 };
 
-constexpr int kCkptStride = 64;   // border-walk steps between two checkpoints (= steps one lane of k_trace_write replays)
-struct CkptRec {                  // walk state every kCkptStride steps of a kept contour: x[0:12) y[12:24) s[24:27), and its contour
-    unsigned state, ci;
+// Border nodes.  A border (outer or hole) is a cycle of (pixel, back-direction) states under the border-following step.  The
+// nodes of a frame are the states that cut those cycles into short segments, all decidable from the 3x3 neighbourhood:
+//   * the start candidates of the sequential raster scan (outer type: foreground with W / NW / N / NE background; hole type:
+//     foreground with E background and NE foreground, i.e. the pixel left of a background pixel whose W and N are foreground),
+//   * cut states: any state on a pixel of the kCutGrid lattice (x or y a multiple of kCutGrid) whose first examined neighbour
+//     (direction s + 1) is background - such a state hugs a background pixel, so its cycle is a real border.
+// k_threshold lists them (packed as below), k_seg walks each node's segment to the next node, k_link follows the node cycles
+// (dozens of hops instead of thousands of pixel steps) to elect the canonical start and to cut the kept borders into write
+// tickets, and k_trace_write replays those in parallel.
+constexpr int kCutGrid = 64;      // power of two, divides the 64-pixel tile width of k_threshold
+constexpr unsigned kNodeCut = 0u, kNodeOuter = 1u, kNodeHole = 2u, kNodeInvalid = 3u;   // type field
+constexpr unsigned kNone = 0xFFFFFFFFu;
+// x[0:12) y[12:24) s[24:27) scale[27:29) type[29:31); bit 31 (NodeRec::state only): the candidate passes the run-top test
+__host__ __device__ inline unsigned pack_node(unsigned x, unsigned y, unsigned s, unsigned scale, unsigned type) {
+    return x | (y << 12) | (s << 24) | (scale << 27) | (type << 29);
+}
+constexpr unsigned kNodeStateMask = 0x1FFFFFFFu;   // x, y, s, scale: identifies the state
+constexpr unsigned kNodePixelMask = 0x18FFFFFFu;   // x, y, scale: identifies the pixel
+struct NodeRec {                  // one segment: from this node's state to the next node's on the same border
+    unsigned state;               // pack_node | top << 31
+    unsigned nxt;                 // index of the next node in the frame's list, kNone when the walk was cut (longer than max_perim)
+    unsigned len;                 // border-following steps to it
+    int area;                     // shoelace partial sum over those steps
+};
+constexpr int kWriteChunk = 64;   // points per write ticket (k_link; k_link_serial: whole segments, at least this many points)
+struct WriteRec {                 // one write ticket: from `state` skip cnt >> 16 steps, then the next cnt & 0xFFFF points go to offset `rel` (cyclic) of contour `ci`
+    unsigned state, ci, rel, cnt;
 };
 
 struct CandRec {                  // quad that passed _findMarkerContours

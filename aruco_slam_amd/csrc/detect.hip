@@ -21,8 +21,19 @@
 #include "detect.h"
 #include <cfloat>
 #include <climits>
+#include <cstdlib>
+#include <algorithm>
 
 namespace aslam {
+
+// direction d = 0..7: E NE N NW W SW S SE (counter-clockwise on the screen)
+__device__ __forceinline__ int dir_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }   // {1,1,0,-1,-1,-1,0,1}+1 packed
+__device__ __forceinline__ int dir_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }   // {0,-1,-1,-1,0,1,1,1}+1 packed
+// first foreground neighbour clockwise from W for a pixel whose NE,N,NW,W are background: E, SE, S, SW
+__device__ __forceinline__ int first_outer(unsigned m) { return (m & 1u) ? 0 : (m & 128u) ? 7 : (m & 64u) ? 6 : 5; }
+// first foreground neighbour clockwise from E: SE, S, SW, W, NW, N, NE = highest set bit among bits 7..1
+__device__ __forceinline__ int first_hole(unsigned m) { return 31 - __clz((int)(m & 0xFEu)); }
+
 
 // ------------------------------------------------------------------------------------------------
 // k_threshold
@@ -57,13 +68,13 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                                                    size_t in_row_step, uint8_t* __restrict__ gray_out,
                                                    uint8_t* __restrict__ nbr, DetectCfg cfg,
                                                    unsigned* __restrict__ starts, unsigned* __restrict__ n_starts,
-                                                   Counters* ctr, int nframes) {
+                                                   unsigned* __restrict__ nodeplane, Counters* ctr, int nframes) {
     __shared__ uint8_t g[LH][LW];
     __shared__ unsigned I[LH + 1][LW + 1];
     __shared__ unsigned long long sRow[kScales][TH + 2];     // threshold decisions of ring row by, columns x0 - 1 .. x0 + 62 (bit = column)
     __shared__ unsigned long long sRing[kScales][2];         // ... of columns x0 + 63 and x0 + 64 (bit = ring row)
     __shared__ unsigned short sLut[512];
-    __shared__ unsigned sStart[kBlockStarts];      // x | y << 12 | scale << 24 | type << 26
+    __shared__ unsigned sStart[kBlockStarts];      // pack_node(x, y, s, scale, type)
     __shared__ unsigned sNStart, sBase;
 
     const int tid = threadIdx.x;
@@ -216,27 +227,29 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         }
         // neighbourhood table: index = N3 | C3 << 3 | S3 << 6 (three pixels west..east of the rows above / at / below) ->
         // bits 0..7 the neighbour mask (bit d = neighbour in direction d is foreground; 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE),
-        // bit 8 outer-type start (foreground, W/NW/N/NE background, not isolated), bit 9 hole-type start (background, W and N foreground)
+        // bit 8 the pixel is foreground, bit 9 it carries a start candidate of the raster scan: outer type (W/NW/N/NE background, not
+        // isolated) or hole type (E background and NE foreground: the pixel left of a background pixel whose W and N are foreground)
         for (int i = tid; i < 512; i += 256) {
             const unsigned n3 = i & 7u, c3 = (i >> 3) & 7u, s3 = (unsigned)i >> 6;
             const unsigned m = ((c3 >> 2) & 1u) | (((n3 >> 2) & 1u) << 1) | (((n3 >> 1) & 1u) << 2) | ((n3 & 1u) << 3) | ((c3 & 1u) << 4) |
                                ((s3 & 1u) << 5) | (((s3 >> 1) & 1u) << 6) | (((s3 >> 2) & 1u) << 7);
             const unsigned fg = (c3 >> 1) & 1u;
             const bool outer = fg && m != 0 && (m & 0x1Eu) == 0;
-            const bool hole = !fg && (m & 0x14u) == 0x14u;
-            sLut[i] = (unsigned short)(m | (outer ? 0x100u : 0u) | (hole ? 0x200u : 0u));
+            const bool hole = fg && (m & 3u) == 2u;
+            sLut[i] = (unsigned short)(m | (fg ? 0x100u : 0u) | ((outer || hole) ? 0x200u : 0u));
         }
     }
     __syncthreads();
     THR_STAMP(3);
 
-    // 4. neighbour masks and border start candidates (staged in LDS, one reservation per tile in the frame's list): a thread
-    //    takes four pixels of a row; six consecutive bits of the three bit rows around them index the table above
+    // 4. neighbour masks and border nodes (common.h: start candidates + cut states; staged in LDS, one reservation per tile in the
+    //    frame's list): a thread takes four pixels of a row; six consecutive bits of the three bit rows around them index the table above
     for (int u = tid; u < TH * TW / 4; u += 256) {
         const int ty = u / (TW / 4), tx4 = (u - ty * (TW / 4)) * 4;
         const int gy = y0 + ty;
+        const bool row_on_grid = (gy & (kCutGrid - 1)) == 0;
         unsigned out[kScales] = {0, 0, 0};
-        unsigned cand = 0;                                          // bit 4 s + j: outer-type start at pixel j of scale s; bit 16 + 4 s + j: hole-type
+        unsigned emit = 0;                                          // bit 4 s + j: pixel j of scale s may carry nodes
 #pragma unroll
         for (int s = 0; s < kScales; s++) {
             unsigned six[3];
@@ -254,24 +267,42 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                     const unsigned idx = ((six[0] >> j) & 7u) | (((six[1] >> j) & 7u) << 3) | (((six[2] >> j) & 7u) << 6);
                     const unsigned t = sLut[idx];
                     out[s] |= (t & 0xFFu) << (8 * j);
-                    cand |= ((t >> 8) & 1u) << (4 * s + j) | ((t >> 9) & 1u) << (16 + 4 * s + j);
+                    const unsigned on_grid = (row_on_grid || ((tx4 + j) & (kCutGrid - 1)) == 0) ? 1u : 0u;    // x0 is a multiple of kCutGrid
+                    emit |= (((t >> 9) | ((t >> 8) & on_grid)) & 1u) << (4 * s + j);
                 }
             }
         }
-        if (cand) {                                                 // one reservation for all start candidates of these four pixels
-            const unsigned both = (cand | (cand >> 16)) & 0xFFFFu;
-            unsigned k = atomicAdd(&sNStart, (unsigned)__popc(both));
-            for (unsigned rest = both; rest; rest &= rest - 1u, k++) {
-                const int bit = __ffs((int)rest) - 1, s = bit >> 2, j = bit & 3;
-                const unsigned ent = (unsigned)(x0 + tx4 + j) | ((unsigned)gy << 12) | ((unsigned)s << 24) | (((cand >> (16 + bit)) & 1u) << 26);
-                if (k < (unsigned)kBlockStarts) {
-                    sStart[k] = ent;
-                } else {                                            // pathological tile (> 1024 candidates): go to the list directly
-                    const unsigned kk = atomicAdd(&n_starts[b], 1u);
-                    if (kk < cfg.cap_starts) starts[(size_t)b * cfg.cap_starts + kk] = ent;
-                    else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
-                }
+        for (unsigned rest = emit; rest; rest &= rest - 1u) {       // rare: a few pixels per tile
+            const int bit = __ffs((int)rest) - 1, s = bit >> 2, j = bit & 3;
+            const unsigned gx = (unsigned)(x0 + tx4 + j);
+            const unsigned m = (out[s] >> (8 * j)) & 0xFFu;         // the pixel is foreground (both bits of the table require it)
+            const bool outer = m != 0 && (m & 0x1Eu) == 0, hole = (m & 3u) == 2u;
+            const unsigned s0 = outer ? (unsigned)first_outer(m) : (unsigned)first_hole(m);
+            unsigned cut = 0;
+            if (row_on_grid || (gx & (kCutGrid - 1)) == 0) cut = m & ~((m >> 1) | (m << 7)) & 0xFFu;   // neighbour s foreground, neighbour s + 1 background
+            if (outer || hole) cut &= ~(1u << s0);                  // the candidate's own state is listed once
+            const unsigned cnt = (unsigned)__popc(cut) + ((outer || hole) ? 1u : 0u);
+            if (cnt == 0) continue;
+            // the nodes of one pixel are consecutive in the frame's list (nodeplane holds the index of the first)
+            const unsigned k = atomicAdd(&sNStart, cnt);
+            const bool staged = k + cnt <= (unsigned)kBlockStarts;
+            unsigned kk = 0;
+            bool fits = true;
+            if (!staged) {                                          // pathological tile (> 1024 nodes): go to the list directly
+                for (unsigned e = k; e < (unsigned)kBlockStarts; e++) sStart[e] = kNone;      // staged slots this pixel does not use
+                kk = atomicAdd(&n_starts[b], cnt);
+                fits = kk + cnt <= cfg.cap_starts;
+                if (fits) nodeplane[((size_t)b * kScales + s) * nbr_plane_bytes(rows, cfg.pitch) + nbr_index((int)gx, gy, cfg.pitch)] = kk;
+                else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
             }
+            unsigned e = 0;
+            auto put = [&](unsigned v) {
+                if (staged) sStart[k + e] = v;
+                else if (fits) starts[(size_t)b * cfg.cap_starts + kk + e] = v;
+                e++;
+            };
+            if (outer || hole) put(pack_node(gx, (unsigned)gy, s0, (unsigned)s, outer ? kNodeOuter : kNodeHole));
+            for (unsigned c2 = cut; c2; c2 &= c2 - 1u) put(pack_node(gx, (unsigned)gy, (unsigned)(__ffs((int)c2) - 1), (unsigned)s, kNodeCut));
         }
         if (gy < rows) {
 #pragma unroll
@@ -288,9 +319,15 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
     if (tid == 0 && ns > 0) sBase = atomicAdd(&n_starts[b], ns);
     __syncthreads();
     for (unsigned i = tid; i < ns; i += 256) {
-        unsigned k = sBase + i;
-        if (k < cfg.cap_starts) starts[(size_t)b * cfg.cap_starts + k] = sStart[i];
-        else atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
+        const unsigned k = sBase + i, e = sStart[i];
+        if (k < cfg.cap_starts) {
+            starts[(size_t)b * cfg.cap_starts + k] = e;
+            if (e != kNone && (i == 0 || ((sStart[i - 1] ^ e) & kNodePixelMask) != 0))        // first node of its pixel
+                nodeplane[((size_t)b * kScales + ((e >> 27) & 3u)) * nbr_plane_bytes(rows, cfg.pitch) +
+                          nbr_index((int)(e & 0xFFFu), (int)((e >> 12) & 0xFFFu), cfg.pitch)] = k;
+        } else {
+            atomicOr(&ctr->overflow, (unsigned)kOvfStarts);
+        }
     }
 #ifdef ASLAM_THR_STAMPS
     THR_STAMP(5);
@@ -339,15 +376,8 @@ __device__ __forceinline__ int ticket_frame(const unsigned* sPre, int nframes, u
 constexpr int kMaxFramesPerCall = 1024;
 
 // ------------------------------------------------------------------------------------------------
-// k_trace
+// k_seg / k_link / k_trace_write : Suzuki-Abe border following without the sequential raster scan, in segments
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int dir_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }   // {1,1,0,-1,-1,-1,0,1}+1 packed
-__device__ __forceinline__ int dir_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }   // {0,-1,-1,-1,0,1,1,1}+1 packed
-// first foreground neighbour clockwise from W for a pixel whose NE,N,NW,W are background: E, SE, S, SW
-__device__ __forceinline__ int first_outer(unsigned m) { return (m & 1u) ? 0 : (m & 128u) ? 7 : (m & 64u) ? 6 : 5; }
-// first foreground neighbour clockwise from E: SE, S, SW, W, NW, N, NE = highest set bit among bits 7..1
-__device__ __forceinline__ int first_hole(unsigned m) { return 31 - __clz((int)(m & 0xFEu)); }
-
 struct Walk {
     int x, y, s;
 };
@@ -361,16 +391,13 @@ __device__ __forceinline__ void walk_step(Walk& w, unsigned m) {
     w.s = (s2 + 4) & 7;
 }
 
-constexpr int kTraceChunk = 64;       // tickets per grab: one per lane (a wave that grabs more sits on long walks while other waves idle)
-constexpr int kLongWalk = 512;       // steps after which a walk makes its wave stop refilling (see k_trace)
+constexpr int kTraceChunk = 64;      // tickets per grab: one per lane
 constexpr int kRunLook = 8;          // pixels of the start candidate's run examined by the two tests below
 
 // A border's canonical start (the state the sequential raster scan starts it from) lies on the FIRST row of the border /
 // hole, so nothing of the same component may sit above the horizontal run it opens.  k_threshold's candidate test only
 // looks at the first pixel of that run; these look kRunLook pixels further (or to the run's end).  They are necessary
-// conditions of being canonical, applied identically when a candidate is picked up and when a walk asks whether it has
-// reached another candidate, so they only discard walks that could never have emitted a contour (e.g. one per stair
-// step of a slanted edge).
+// conditions of being canonical, so a candidate that fails them never competes for a border (k_link).
 //   outer: foreground run starting at (x, y) whose first pixel has W/NW/N/NE background: no later pixel of the run
 //          may have a N or NE foreground neighbour.
 //   hole : background run starting at (x, y) (W and N foreground): every pixel of the run must have N foreground (the
@@ -395,60 +422,56 @@ __device__ __forceinline__ bool run_is_top_hole(const uint8_t* __restrict__ plan
     return true;
 }
 
-// Work-queue kernel.  Every lane is a small state machine (idle -> validate walk -> write walk -> idle); idle lanes are
-// refilled from the queue every iteration with ONE atomic per wave, so a wave never waits for its longest walk.
-// Tickets number the start candidates of the whole call; `pre` holds the per-frame prefix of their counts.
-__global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, DetectCfg cfg, int nframes,
-                                              const unsigned* __restrict__ starts,
-                                              const unsigned* __restrict__ pre, Counters* ctr,
-                                              ContourRec* __restrict__ contours, unsigned* __restrict__ n_contours,
-                                              unsigned* __restrict__ n_points, CkptRec* __restrict__ ckpt,
-                                              unsigned* __restrict__ n_ckpt, unsigned* __restrict__ lane_ckpt) {
-    __shared__ unsigned sPre[kMaxFramesPerCall + 1];
-    // One border-following step as a table: (neighbour mask m, back direction s) -> dx + 1 | dy + 1 << 2 | new s << 4 | "this state is
-    // the start state of an outer-type candidate" << 7 | "... of a hole-type candidate" << 8.  A walk is one dependent chain and the
-    // launch lasts as long as its longest one, so the ~35 instructions of walk_step / first_outer / first_hole become one LDS read.
-    __shared__ unsigned short sStep[256 * 8];
-    const int lane = threadIdx.x & 63;
-    for (int i = lane; i < 256 * 8; i += 64) {
+// One border-following step as a table: (neighbour mask m, back direction s) -> dx + 1 | dy + 1 << 2 | new s << 4 | "this state is an
+// outer-type start candidate" << 7 | "... a hole-type one" << 8 | "the first examined neighbour s + 1 is background: a cut state where
+// the pixel lies on the kCutGrid lattice" << 9.  A walk is one dependent chain, so the ~35 instructions of walk_step become one LDS read.
+__device__ __forceinline__ void build_step_table(unsigned short* sStep, int tid, int nthreads) {
+    for (int i = tid; i < 256 * 8; i += nthreads) {
         const unsigned m = (unsigned)i >> 3;
         const int sd = i & 7;
         Walk t{0, 0, sd};
         if (m != 0) walk_step(t, m);
-        const bool co = (m & 0x1Eu) == 0 && sd == first_outer(m);
+        const bool co = m != 0 && (m & 0x1Eu) == 0 && sd == first_outer(m);
         const bool ch = (m & 3u) == 2u && sd == first_hole(m);
-        sStep[i] = (unsigned short)((unsigned)(t.x + 1) | ((unsigned)(t.y + 1) << 2) | ((unsigned)t.s << 4) | (co ? 0x80u : 0u) | (ch ? 0x100u : 0u));
+        const bool cut = ((m >> sd) & 1u) != 0 && ((m >> ((sd + 1) & 7)) & 1u) == 0;
+        sStep[i] = (unsigned short)((unsigned)(t.x + 1) | ((unsigned)(t.y + 1) << 2) | ((unsigned)t.s << 4) | (co ? 0x80u : 0u) | (ch ? 0x100u : 0u) |
+                                    (cut ? 0x200u : 0u));
     }
+}
+__device__ __forceinline__ bool on_cut_grid(int x, int y) { return ((x & (kCutGrid - 1)) == 0) || ((y & (kCutGrid - 1)) == 0); }
+
+// k_seg: work-queue kernel, one lane per node (ticket = node of the whole call; `pre` = per-frame prefix of the node counts).
+// Every lane is a small state machine (idle -> walk -> idle); idle lanes are refilled from the queue with one atomic per 64
+// tickets.  A lane walks from its node's state until it stands on the next node of the border, finds that node's index through the
+// node plane, and records (next, steps, shoelace partial sum).  (Stopping only at candidates that pass the run-top test would
+// shorten the node cycles, but the test is up to eight dependent loads in the middle of a wave's walk loop: measured slower.)
+__global__ __launch_bounds__(64) void k_seg(const uint8_t* __restrict__ nbr, DetectCfg cfg, int nframes,
+                                            const unsigned* __restrict__ starts, const unsigned* __restrict__ n_starts,
+                                            const unsigned* __restrict__ nodeplane,
+                                            const unsigned* __restrict__ pre, Counters* ctr,
+                                            NodeRec* __restrict__ nodes) {
+    __shared__ unsigned sPre[kMaxFramesPerCall + 1];
+    __shared__ unsigned short sStep[256 * 8];
+    const int lane = threadIdx.x & 63;
+    build_step_table(sStep, lane, 64);
     for (int i = lane; i <= nframes; i += 64) sPre[i] = pre[i];
     __syncthreads();
     const unsigned total = sPre[nframes];
     const int pitch = cfg.pitch, cols = cfg.cols;
+    const size_t plane_bytes = nbr_plane_bytes(cfg.rows, pitch);
 
-#ifdef ASLAM_TRACE_TIMELINE
-    const unsigned long long tl_start = wall_clock64();
-    unsigned tl_steps = 0, tl_tickets = 0, tl_iters = 0, tl_maxn = 0;
-#endif
-    int mode = 0;                       // 0 idle, 1 walk, 2 hand the checkpoints of a kept contour over
+    int mode = 0;                       // 0 idle, 1 walking
     bool drained = false;               // the queue is empty (wave-uniform)
     unsigned lo = 0, hi = 0;            // the wave's private ticket range (wave-uniform)
     const uint8_t* plane = nbr;
+    const unsigned* idplane = nodeplane;
     Walk w{0, 0, 0};
-    int sx = 0, sy = 0, s0 = 0, key0 = 0, n = 0, wi = 0, f = 0;
-    int kmin_outer = INT_MAX, kmin_hole = INT_MAX, kpos_outer = 0, kpos_hole = 0;
-    unsigned* myck = lane_ckpt + ((size_t)blockIdx.x * 64 + lane) * cfg.ckpt_per_walk;   // this lane's checkpoints of the walk in progress
-    CkptRec* ckdst = ckpt;
-    unsigned ci_keep = 0;
-    unsigned type = 0, sc = 0;
-    int area = 0;                       // twice the signed area (shoelace); |step term| <= 4095, <= 5120 steps: fits 32 bits
+    int n = 0, f = 0, area = 0;         // twice the signed area (shoelace); |step term| <= 4095, <= max_perim steps: fits 32 bits
+    unsigned self = 0, state0 = 0;
 
     for (;;) {
-        // ---- refill idle lanes from the wave's private ticket range; a new range costs one atomic per kTraceChunk tickets ----
         const unsigned long long idle = __ballot(mode == 0);
-        // A wave that carries a long walk (a border of thousands of pixels is ONE dependent chain of byte loads, and the kernel
-        // cannot end before the longest of them does) stops drawing new ticket ranges: picking candidates up costs every lane
-        // of the wave several dependent loads per iteration, which the long walk would pay on each of its steps.
-        const bool long_walk = __ballot(mode == 1 && n > kLongWalk) != 0ull;
-        if (idle != 0ull && !drained && !(lo == hi && long_walk)) {
+        if (idle != 0ull && !drained) {
             if (lo == hi) {                                       // wave-uniform
                 unsigned base = 0;
                 if (lane == 0) base = atomicAdd(&ctr->q_trace, (unsigned)kTraceChunk);
@@ -462,155 +485,378 @@ __global__ __launch_bounds__(64) void k_trace(const uint8_t* __restrict__ nbr, D
             if (mode == 0 && rank < take) {
                 const unsigned ticket = lo + rank;
                 if (!(ticket >= sPre[f] && ticket < sPre[f + 1])) f = ticket_frame(sPre, nframes, ticket);
-                const unsigned e = starts[(size_t)f * cfg.cap_starts + (ticket - sPre[f])];
-                int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
-                sc = (e >> 24) & 3u;
-                type = (e >> 26) & 1u;
-                plane = nbr + ((size_t)f * kScales + sc) * nbr_plane_bytes(cfg.rows, pitch);
-                key0 = y * cols + x;
-                const bool top = type ? run_is_top_hole(plane, x, y, pitch, cols)
-                                      : run_is_top_outer(plane, x, y, pitch, plane[nbr_index(x, y, pitch)]);
-                if (top) {
-                    if (type) x -= 1;                              // hole border starts on the pixel left of the hole
-                    const unsigned m0 = plane[nbr_index(x, y, pitch)];
-                    s0 = type ? first_hole(m0) : first_outer(m0);
-                    sx = x; sy = y;
-                    w = Walk{sx, sy, s0};
+                self = ticket - sPre[f];
+                const unsigned e = starts[(size_t)f * cfg.cap_starts + self];
+                const unsigned type = (e >> 29) & 3u;
+                if (type == kNodeInvalid) {                        // a staged slot k_threshold left unused
+                    nodes[(size_t)f * cfg.cap_starts + self] = NodeRec{kNone, kNone, 0u, 0};
+                } else {
+                    const int x = (int)(e & 0xFFFu), y = (int)((e >> 12) & 0xFFFu);
+                    const unsigned sc = (e >> 27) & 3u;
+                    plane = nbr + ((size_t)f * kScales + sc) * plane_bytes;
+                    idplane = nodeplane + ((size_t)f * kScales + sc) * plane_bytes;
+                    bool top = false;
+                    if (type == kNodeOuter) top = run_is_top_outer(plane, x, y, pitch, plane[nbr_index(x, y, pitch)]);
+                    else if (type == kNodeHole) top = run_is_top_hole(plane, x + 1, y, pitch, cols);
+                    state0 = e | (top ? 0x80000000u : 0u);
+                    w = Walk{x, y, (int)((e >> 24) & 7u)};
                     area = 0;
                     n = 0;
-                    kmin_outer = type ? INT_MAX : key0;
-                    kmin_hole = type ? key0 : INT_MAX;
-                    kpos_outer = kpos_hole = 0;
                     mode = 1;
                 }
             }
-#ifdef ASLAM_TRACE_TIMELINE
-            tl_tickets += take;
-#endif
             lo += take;
         }
-#ifdef ASLAM_TRACE_TIMELINE
-        tl_iters++; tl_steps += (unsigned)__popcll(__ballot(mode == 1)); { int nn = mode == 1 ? n : 0; for (int o = 32; o > 0; o >>= 1) nn = max(nn, __shfl_xor(nn, o)); tl_maxn = max(tl_maxn, (unsigned)nn); }
-#endif
         if (__ballot(mode != 0) == 0ull) {
             if (drained) break;
-            continue;                                              // every candidate just picked up was discarded: fetch more
+            continue;
         }
-
-        // ---- one step per busy lane; when nothing can be picked up (every lane busy, queue drained, or this wave carries a long walk
-        //      and has used up its ticket range) the bookkeeping above cannot change anything: several steps per round - a border walk
-        //      is one dependent chain, and the launch lasts as long as its longest one: every instruction of a step counts ----
-        const int reps = (idle == 0ull || drained || (lo == hi && long_walk)) ? 16 : 1;   // wave-uniform
+        // several steps per round when nothing can be picked up anyway
+        const int reps = (idle == 0ull || drained) ? 16 : 4;      // wave-uniform
         for (int rep = 0; rep < reps; rep++) {
-        if (mode == 1) {
-            const unsigned m = plane[nbr_index(w.x, w.y, pitch)];
-            bool dead = false;
-            // Is this state the start state of a scan candidate (of either type)?  A smaller key that passes the run test
-            // belongs to a walker that will do (or hand on) this border: stop.  Otherwise remember the smallest key per
-            // type: whoever closes the border needs the first start of the border's own type (outer / hole).
-            const unsigned st = sStep[(m << 3) | (unsigned)w.s];
-            const bool co = (st & 0x80u) != 0, ch = (st & 0x100u) != 0;
-            if (co || ch) {
-                const int key = w.y * cols + w.x + (ch ? 1 : 0);
-                if (key < key0) dead = ch ? run_is_top_hole(plane, w.x + 1, w.y, pitch, cols) : run_is_top_outer(plane, w.x, w.y, pitch, m);
-                if (ch) { if (key < kmin_hole) { kmin_hole = key; kpos_hole = n; } }
-                else if (key < kmin_outer) { kmin_outer = key; kpos_outer = n; }
+            if (mode == 1) {
+                const unsigned m = plane[nbr_index(w.x, w.y, pitch)];
+                const unsigned st = sStep[(m << 3) | (unsigned)w.s];
+                const bool arrived = n > 0 && ((st & 0x180u) != 0 || ((st & 0x200u) != 0 && on_cut_grid(w.x, w.y)));
+                if (arrived) {
+                    // the node standing on this state: the nodes of a pixel are consecutive in the frame's list
+                    const unsigned want = pack_node((unsigned)w.x, (unsigned)w.y, (unsigned)w.s, (state0 >> 27) & 3u, 0u);
+                    const unsigned cnt = min(n_starts[f], cfg.cap_starts);
+                    unsigned id = idplane[nbr_index(w.x, w.y, pitch)];
+                    unsigned found = kNone;
+                    for (int t = 0; t < 9 && id < cnt; t++, id++) {
+                        const unsigned e2 = starts[(size_t)f * cfg.cap_starts + id];
+                        if (((e2 ^ want) & kNodePixelMask) != 0) break;
+                        if (((e2 ^ want) & kNodeStateMask) == 0) { found = id; break; }
+                    }
+                    nodes[(size_t)f * cfg.cap_starts + self] = NodeRec{state0, found, (unsigned)n, area};
+                    mode = 0;
+                } else {
+                    const int ddx = (int)(st & 3u) - 1, ddy = (int)((st >> 2) & 3u) - 1;
+                    area += w.x * ddy - ddx * w.y;                 // = px * (py + dy) - (px + dx) * py, unit steps in small integers
+                    w.x += ddx; w.y += ddy; w.s = (int)((st >> 4) & 7u);
+                    n++;
+                    if (n > cfg.max_perim) {                       // no kept border is that long: cut
+                        nodes[(size_t)f * cfg.cap_starts + self] = NodeRec{state0, kNone, (unsigned)n, area};
+                            mode = 0;
+                    }
+                }
             }
-            if (dead) {
+            if (__ballot(mode != 0) == 0ull) break;
+        }
+    }
+}
+
+// k_link: the node cycles of one frame, resolved by one workgroup in LDS with pointer jumping (no lane ever walks a cycle):
+//   1. election: every node learns the smallest node index of its cycle (its leader) - (leader, pointer) pairs in one 32-bit
+//      word, pointer doubling for ceil(log2(nodes)) + 1 rounds; a cut segment poisons everything that leads into it;
+//   2. ranking: every node learns its distance to the leader along the border ((distance, pointer) pairs, doubling until every
+//      pointer stands on the leader); the leader's own distance is the border's length n;
+//   3. borders with min_perim <= n <= max_perim get a slot; all their nodes add their shoelace sums into it and the start
+//      candidates that pass the run-top test their keys (LDS atomics);
+//   4. the first candidate of the border's own type (outer / hole, by the sign of the area) - the start the sequential scan would
+//      have used - emits the contour;
+//   5. every node of an emitted border writes the tickets of the 64-point blocks of the contour that begin inside its segment.
+// A frame with more nodes than the LDS image holds, or more borders than slots, is left to k_link_serial (flag in link_todo).
+__device__ __forceinline__ int node_key(unsigned state, int cols) {
+    return (int)((state >> 12) & 0xFFFu) * cols + (int)(state & 0xFFFu) + (((state >> 29) & 3u) == kNodeHole ? 1 : 0);
+}
+constexpr int kLinkThreads = 1024;
+constexpr unsigned kLinkLdsNodes = 12288;        // x 10 B = 120 KB
+constexpr unsigned kLinkSlots = 1024;            // x 32 B = 32 KB
+struct LinkSlot {
+    int area, kmin_outer, kmin_hole;
+    unsigned n, ci, wbase, pos_canon, pad;
+};
+__global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsigned* __restrict__ n_starts, Counters* ctr,
+                                                       const NodeRec* __restrict__ nodes, unsigned lds_nodes, unsigned* __restrict__ link_todo,
+                                                       ContourRec* __restrict__ contours, unsigned* __restrict__ n_contours,
+                                                       unsigned* __restrict__ n_points, WriteRec* __restrict__ wlist, unsigned* __restrict__ n_write) {
+    ASLAM_DYN_LDS(dyn_lds);
+    __shared__ unsigned sNSlots, sActive;
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x;
+    const int cols = cfg.cols;
+    const unsigned nn = min(n_starts[f], cfg.cap_starts);
+    const NodeRec* gn = nodes + (size_t)f * cfg.cap_starts;
+    if (nn > lds_nodes) {                                      // uniform
+        if (tid == 0) link_todo[f] = 1u;
+        return;
+    }
+    unsigned* sLink = reinterpret_cast<unsigned*>(dyn_lds);                     // next | steps << 16 (0xFFFF: none / saturated)
+    unsigned* sPair = sLink + lds_nodes;                                        // election: leader + 1 | pointer << 16; ranking: distance | pointer << 16
+    LinkSlot* sSlot = reinterpret_cast<LinkSlot*>(sPair + lds_nodes);
+    unsigned short* sLead = reinterpret_cast<unsigned short*>(sSlot + kLinkSlots);   // leader + 1 (0: poisoned); of a leader: 0x8000 | slot, 0 without one
+    if (tid == 0) { sNSlots = 0; sActive = 0; }
+
+    // ---- 1. election ----
+    for (unsigned i = tid; i < nn; i += kLinkThreads) {
+        const NodeRec r = gn[i];
+        const bool dead = r.state == kNone || r.nxt == kNone || r.nxt >= nn;
+        sLink[i] = (dead ? 0xFFFFu : r.nxt) | (min(r.len, 0xFFFFu) << 16);
+        sPair[i] = dead ? (0u | (i << 16)) : ((i + 1u) | (r.nxt << 16));
+    }
+    __syncthreads();
+    int rounds = 1;
+    while ((1u << rounds) < nn) rounds++;
+    for (int r = 0; r <= rounds; r++) {
+        for (unsigned i = tid; i < nn; i += kLinkThreads) {
+            const unsigned w = sPair[i], wp = sPair[w >> 16];
+            sPair[i] = min(w & 0xFFFFu, wp & 0xFFFFu) | (wp & 0xFFFF0000u);
+        }
+        __syncthreads();
+    }
+    // ---- 2. ranking ----
+    for (unsigned i = tid; i < nn; i += kLinkThreads) {
+        const unsigned lead = sPair[i] & 0xFFFFu;
+        sLead[i] = (unsigned short)lead;
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < nn; i += kLinkThreads) sPair[i] = sLead[i] ? ((sLink[i] >> 16) | (sLink[i] << 16)) : 0u;     // (steps, next)
+    __syncthreads();
+    for (int r = 0; r <= rounds + 1; r++) {
+        bool active = false;
+        for (unsigned i = tid; i < nn; i += kLinkThreads) {
+            const unsigned lead = sLead[i];
+            if (lead == 0) continue;
+            const unsigned w = sPair[i], p = w >> 16;
+            if (p == lead - 1u) continue;                      // the pointer stands on the leader
+            const unsigned wp = sPair[p];
+            sPair[i] = min((w & 0xFFFFu) + (wp & 0xFFFFu), 0xFFFFu) | (wp & 0xFFFF0000u);
+            active = true;
+        }
+        if (active) sActive = (unsigned)r + 1u;                // (a round number: never reset, so no write races with a reset)
+        __syncthreads();
+        const bool any = sActive == (unsigned)r + 1u;
+        __syncthreads();
+        if (!any) break;                                       // uniform
+    }
+    // ---- 3. slots and sums ----
+    for (unsigned i = tid; i < nn; i += kLinkThreads) {
+        if (sLead[i] != i + 1u) continue;                      // leaders only
+        const unsigned n = sPair[i] & 0xFFFFu;                 // all the way round
+        unsigned v = 0;
+        if ((int)n >= cfg.min_perim && (int)n <= cfg.max_perim && (sPair[i] >> 16) == i) {
+            const unsigned slot = atomicAdd(&sNSlots, 1u);
+            if (slot < kLinkSlots) {
+                sSlot[slot] = LinkSlot{0, INT_MAX, INT_MAX, n, kNone, 0u, 0u, 0u};
+                v = 0x8000u | slot;
+            }
+        }
+        sLead[i] = (unsigned short)v;
+    }
+    __syncthreads();
+    if (sNSlots > kLinkSlots) {                                // uniform; nothing has left the workgroup yet
+        if (tid == 0) link_todo[f] = 1u;
+        return;
+    }
+    if (tid == 0) link_todo[f] = 0u;
+    auto slot_of = [&](unsigned i) -> int {                    // the slot of node i's border, -1 without one
+        unsigned v = sLead[i];
+        if (v == 0) return -1;
+        if (v < 0x8000u) v = sLead[v - 1u];
+        return v >= 0x8000u ? (int)(v & 0x7FFFu) : -1;
+    };
+    for (unsigned i = tid; i < nn; i += kLinkThreads) {
+        const int sl = slot_of(i);
+        if (sl < 0) continue;
+        const NodeRec r = gn[i];
+        atomicAdd(&sSlot[sl].area, r.area);
+        const unsigned type = (r.state >> 29) & 3u;
+        if ((r.state >> 31) && type == kNodeOuter) atomicMin(&sSlot[sl].kmin_outer, node_key(r.state, cols));
+        if ((r.state >> 31) && type == kNodeHole) atomicMin(&sSlot[sl].kmin_hole, node_key(r.state, cols));
+    }
+    __syncthreads();
+    // ---- 4. the canonical start emits the contour ----
+    for (unsigned i = tid; i < nn; i += kLinkThreads) {
+        const int sl = slot_of(i);
+        if (sl < 0) continue;
+        const NodeRec r = gn[i];
+        const unsigned type = (r.state >> 29) & 3u;
+        if (!(r.state >> 31) || (type != kNodeOuter && type != kNodeHole)) continue;
+        const LinkSlot s = sSlot[sl];
+        const bool is_hole = s.area > 0;                       // outer borders run counter-clockwise on screen
+        if (type != (is_hole ? kNodeHole : kNodeOuter)) continue;
+        const int ckey = is_hole ? s.kmin_hole : s.kmin_outer;
+        if (node_key(r.state, cols) != ckey) continue;
+        const unsigned n = s.n, wcap = (n + 63u) / 64u;
+        const unsigned ci = atomicAdd(&n_contours[f], 1u);
+        const unsigned off = atomicAdd(&n_points[f], n);
+        const unsigned wbase = atomicAdd(&n_write[f], wcap);
+        const unsigned sc = (r.state >> 27) & 3u;
+        const int cx = ckey % cols - (is_hole ? 1 : 0), cy = ckey / cols;
+        if (ci >= cfg.cap_contours) {
+            atomicOr(&ctr->overflow, (unsigned)kOvfContours);
+        } else if ((unsigned long long)off + n > cfg.cap_points || (unsigned long long)wbase + wcap > cfg.cap_write) {
+            atomicOr(&ctr->overflow, (unsigned)kOvfPoints);
+            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, 0u, 0u, (short)cx, (short)cy, 0, {0u, 0u}};
+        } else {
+            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, n, off, (short)cx, (short)cy,
+                                                                    (int)((r.state >> 24) & 7u), {0u, 0u}};
+            const unsigned dist = sPair[i] & 0xFFFFu;          // to the leader; the leader's own is n
+            sSlot[sl].pos_canon = n - dist;
+            sSlot[sl].wbase = wbase;
+            sSlot[sl].ci = ci;
+        }
+    }
+    __syncthreads();
+    // ---- 5. write tickets: the 64-point blocks of the contour that begin inside this node's segment ----
+    for (unsigned i = tid; i < nn; i += kLinkThreads) {
+        const int sl = slot_of(i);
+        if (sl < 0) continue;
+        const LinkSlot s = sSlot[sl];
+        if (s.ci == kNone) continue;
+        const unsigned n = s.n, len = sLink[i] >> 16;
+        unsigned rel = (n - (sPair[i] & 0xFFFFu)) + n - s.pos_canon;          // position after the canonical start, mod n
+        while (rel >= n) rel -= n;
+        const unsigned state = gn[i].state;
+        WriteRec* wl = wlist + (size_t)f * cfg.cap_write + s.wbase;
+        for (unsigned b = (rel + 63u) / 64u; 64u * b < min(rel + len, n); b++)
+            wl[b] = WriteRec{state, s.ci, 64u * b, min(64u, n - 64u * b) | ((64u * b - rel) << 16)};
+    }
+}
+
+// k_link_serial: the frames k_link left (link_todo), through global memory, one workgroup per frame.  One lane per node; only
+// start candidates that pass the run-top test do anything: such a lane hops from node to node along its border, one hop per round,
+// while the idle lanes of its wave are refilled from the frame's ticket counter.  A candidate with a smaller key that also passes
+// the test belongs to a lane that will do (or hand on) this border: stop.  The lane that gets back to its own node has the
+// smallest surviving key of the border; it emits the contour from the first candidate of the border's own type, then goes
+// round once more and cuts the border into write tickets: runs of whole segments of at least kWriteChunk points each.
+__global__ __launch_bounds__(512) void k_link_serial(DetectCfg cfg, const unsigned* __restrict__ n_starts, Counters* ctr,
+                                                     const NodeRec* __restrict__ nodes, const unsigned* __restrict__ link_todo,
+                                                     ContourRec* __restrict__ contours, unsigned* __restrict__ n_contours,
+                                                     unsigned* __restrict__ n_points, WriteRec* __restrict__ wlist, unsigned* __restrict__ n_write) {
+    __shared__ unsigned sNext;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int f = blockIdx.x;
+    if (link_todo[f] == 0u) return;                            // uniform
+    const int cols = cfg.cols;
+    const unsigned nn = min(n_starts[f], cfg.cap_starts);
+    const NodeRec* fn = nodes + (size_t)f * cfg.cap_starts;
+    if (tid == 0) sNext = 0;
+    __syncthreads();
+
+    int mode = 0;                       // 0 idle, 1 first lap (election), 2 second lap (write tickets)
+    bool drained = false;
+    unsigned lo = 0, hi = 0;
+    unsigned self = 0, n = 0, hops = 0;
+    int area = 0, key0 = 0;
+    int kmin_outer = INT_MAX, kmin_hole = INT_MAX;
+    unsigned kpos_outer = 0, kpos_hole = 0;
+    NodeRec cur{0u, 0u, 0u, 0};
+    unsigned ci = 0, off = 0, kpos = 0, id = 0, pos = 0, wbase = 0, wcount = 0, wcap = 0, chunk_state = 0, chunk_rel = 0, chunk_len = 0, sc = 0;
+    int ckey = 0, s_canon = 0;
+    bool is_hole = false;
+
+    for (;;) {
+        const unsigned long long idle = __ballot(mode == 0);
+        if (idle != 0ull && !drained) {
+            if (lo == hi) {                                       // wave-uniform
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&sNext, (unsigned)kTraceChunk);
+                base = __shfl(base, 0);
+                lo = base;
+                hi = min(base + (unsigned)kTraceChunk, nn);
+                if (lo >= nn) { drained = true; lo = hi = 0; }
+            }
+            const unsigned take = min((unsigned)__popcll(idle), hi - lo);
+            const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+            if (mode == 0 && rank < take) {
+                self = lo + rank;
+                cur = fn[self];
+                const unsigned type = (cur.state >> 29) & 3u;
+                if (cur.state != kNone && (type == kNodeOuter || type == kNodeHole) && (cur.state >> 31)) {
+                    key0 = node_key(cur.state, cols);
+                    kmin_outer = type == kNodeOuter ? key0 : INT_MAX;
+                    kmin_hole = type == kNodeHole ? key0 : INT_MAX;
+                    kpos_outer = kpos_hole = 0;
+                    sc = (cur.state >> 27) & 3u;
+                    n = 0; area = 0; hops = 0;
+                    mode = 1;
+                }
+            }
+            lo += take;
+        }
+        if (__ballot(mode != 0) == 0ull) {
+            if (drained) break;
+            continue;
+        }
+        if (mode == 1) {
+            n += cur.len;
+            area += cur.area;
+            const unsigned nx = cur.nxt;
+            if (nx == self) {
+                // closed: this lane holds the smallest surviving key of the border
+                mode = 0;
+                is_hole = area > 0;                                // outer borders run counter-clockwise on screen
+                ckey = is_hole ? kmin_hole : kmin_outer;
+                if (ckey != INT_MAX && (int)n >= cfg.min_perim && (int)n <= cfg.max_perim) {
+                    kpos = is_hole ? kpos_hole : kpos_outer;
+                    wcap = n / (unsigned)kWriteChunk + 1u;         // every ticket but the last covers >= kWriteChunk points
+                    ci = atomicAdd(&n_contours[f], 1u);
+                    off = atomicAdd(&n_points[f], n);
+                    wbase = atomicAdd(&n_write[f], wcap);
+                    const int cx = ckey % cols - (is_hole ? 1 : 0), cy = ckey / cols;
+                    if (ci >= cfg.cap_contours) {
+                        atomicOr(&ctr->overflow, (unsigned)kOvfContours);
+                    } else if ((unsigned long long)off + n > cfg.cap_points || (unsigned long long)wbase + wcap > cfg.cap_write) {
+                        atomicOr(&ctr->overflow, (unsigned)kOvfPoints);
+                        contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, 0u, 0u, (short)cx, (short)cy, 0, {0u, 0u}};
+                    } else {
+                        id = self; pos = 0; hops = 0; wcount = 0; chunk_len = 0; s_canon = 0;
+                        mode = 2;
+                    }
+                }
+            } else if (nx == kNone || n > (unsigned)cfg.max_perim || ++hops > nn) {
                 mode = 0;
             } else {
-                if ((n & (kCkptStride - 1)) == 0) myck[n / kCkptStride] = (unsigned)w.x | ((unsigned)w.y << 12) | ((unsigned)w.s << 24);
-                const int ddx = (int)(st & 3u) - 1, ddy = (int)((st >> 2) & 3u) - 1;
-                area += w.x * ddy - ddx * w.y;                     // = px * (py + dy) - (px + dx) * py, unit steps in small integers
-                w.x += ddx; w.y += ddy; w.s = (int)((st >> 4) & 7u);
-                n++;
-                if (w.x == sx && w.y == sy && w.s == s0) {
-                    // closed by the smallest surviving key on this border: emit it from the start the sequential scan would
-                    // have used = the first candidate of the border's own type
-                    const bool is_hole = area > 0;                 // outer borders run counter-clockwise on screen
-                    const int ckey = is_hole ? kmin_hole : kmin_outer;
-                    const bool keep = ckey != INT_MAX && n >= cfg.min_perim && n <= cfg.max_perim;
-                    mode = 0;
-                    if (keep) {
-                        const int cx = ckey % cols - (is_hole ? 1 : 0), cy = ckey / cols;
-                        const unsigned mc = plane[nbr_index(cx, cy, pitch)];
-                        const int cs = is_hole ? first_hole(mc) : first_outer(mc);
-                        const unsigned ncp = ((unsigned)n + kCkptStride - 1) / kCkptStride;
-                        const unsigned ci = atomicAdd(&n_contours[f], 1u);
-                        const unsigned off = atomicAdd(&n_points[f], (unsigned)n);
-                        const unsigned cko = atomicAdd(&n_ckpt[f], ncp);
-                        if (ci >= cfg.cap_contours) {
-                            atomicOr(&ctr->overflow, (unsigned)kOvfContours);
-                        } else if ((unsigned long long)off + (unsigned)n > cfg.cap_points || (unsigned long long)cko + ncp > cfg.cap_ckpt) {
-                            atomicOr(&ctr->overflow, (unsigned)kOvfPoints);
-                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, 0u, 0u, (short)cx, (short)cy, cs, 0u, 0};
-                        } else {
-                            contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, (unsigned)n, off, (short)cx, (short)cy, cs,
-                                                                                    cko, is_hole ? kpos_hole : kpos_outer};
-                            ckdst = ckpt + (size_t)f * cfg.cap_ckpt + cko;
-                            ci_keep = ci;
-                            wi = 0;
-                            n = (int)ncp;
-                            mode = 2;
-                        }
-                    }
-                } else if (n > cfg.max_perim) {
-                    mode = 0;
+                cur = fn[nx];
+                const unsigned t2 = (cur.state >> 29) & 3u;
+                if (t2 == kNodeOuter || t2 == kNodeHole) {
+                    const int key = node_key(cur.state, cols);
+                    if (key < key0 && (cur.state >> 31)) mode = 0;  // a smaller canonical candidate owns this border
+                    if (t2 == kNodeHole) { if (key < kmin_hole) { kmin_hole = key; kpos_hole = n; } }
+                    else if (key < kmin_outer) { kmin_outer = key; kpos_outer = n; }
                 }
             }
         } else if (mode == 2) {
-            ckdst[wi] = CkptRec{myck[wi], ci_keep};           // one checkpoint per iteration (at most cfg.ckpt_per_walk)
-            if (++wi >= n) mode = 0;
-        }
-        if (reps > 1 && __ballot(mode != 0) == 0ull) break;
-        }
-    }
-#ifdef ASLAM_TRACE_TIMELINE
-    if (nframes >= 64) {
-        // per-wave record in the (now dead) walk-checkpoint scratch; the last wave out prints the distribution
-        auto tlw = [&](unsigned w) { return reinterpret_cast<unsigned long long*>(lane_ckpt + (size_t)w * 64 * cfg.ckpt_per_walk); };   // each wave's own (dead) scratch
-        unsigned long long* tl = nullptr; (void)tl;
-        unsigned* cnt = &ctr->pad[0];
-        __syncthreads();
-        if (lane == 0) {
-            const unsigned long long t1 = wall_clock64();
-            unsigned long long* me = tlw(blockIdx.x);
-            me[0] = tl_start; me[1] = t1;
-            me[2] = ((unsigned long long)tl_iters << 32) | tl_steps; me[3] = ((unsigned long long)tl_maxn << 32) | tl_tickets;
-            __threadfence();
-            const unsigned done = atomicAdd(cnt, 1u);
-            if (done == gridDim.x - 1) {
-                unsigned long long t0 = ~0ull, tend = 0;
-                for (unsigned w = 0; w < gridDim.x; w++) { t0 = min(t0, tlw(w)[0]); tend = max(tend, tlw(w)[1]); }
-                unsigned hist[10] = {0}; unsigned long long steps = 0, tickets = 0; unsigned maxit = 0, maxn = 0; double avgit = 0;
-                for (unsigned w = 0; w < gridDim.x; w++) {
-                    const unsigned long long* tl = tlw(w);
-                    const double frac = (double)(tl[1] - t0) / (double)(tend - t0);
-                    hist[min(9, (int)(frac * 10))]++;
-                    steps += tl[2] & 0xFFFFFFFFull; tickets += tl[3] & 0xFFFFFFFFull;
-                    maxit = max(maxit, (unsigned)(tl[2] >> 32)); maxn = max(maxn, (unsigned)(tl[3] >> 32)); avgit += (double)(tl[2] >> 32);
-                }
-                printf("TL frames %d waves %u duration %.1f us | waves finishing per tenth of it: %u %u %u %u %u %u %u %u %u %u | lane-steps %llu tickets %llu | iterations avg %.0f max %u | longest walk %u steps\n",
-                       nframes, gridDim.x, (double)(tend - t0) / 100.0, hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], hist[9], steps, tickets,
-                       avgit / gridDim.x, maxit, maxn);
-                *cnt = 0;
+            // point 0 of the contour = the canonical start = walk step kpos of this lane
+            const NodeRec r = fn[id];
+            unsigned rel = pos + n - kpos;
+            if (rel >= n) rel -= n;
+            if (rel == 0) s_canon = (int)((r.state >> 24) & 7u);
+            if (chunk_len == 0) { chunk_state = r.state; chunk_rel = rel; }
+            chunk_len += r.len;
+            pos += r.len;
+            id = r.nxt;
+            const bool done = id == self || ++hops > nn;
+            WriteRec* wl = wlist + (size_t)f * cfg.cap_write + wbase;
+            if (chunk_len >= (unsigned)kWriteChunk || done) {
+                if (wcount < wcap) wl[wcount++] = WriteRec{chunk_state, ci, chunk_rel, chunk_len};   // (no skip)
+                chunk_len = 0;
+            }
+            if (done) {
+                for (; wcount < wcap; wcount++) wl[wcount] = WriteRec{0u, kNone, 0u, 0u};     // reserved, not needed
+                contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, n, off,
+                                                                        (short)(ckey % cols - (is_hole ? 1 : 0)), (short)(ckey / cols), s_canon, {0u, 0u}};
+                mode = 0;
             }
         }
     }
-#endif
 }
 
-// k_trace_write: the points of every kept contour, kCkptStride of them per lane: replay the border walk from a checkpoint.
-// Tickets number the checkpoints of the whole call (`pre` = per-frame prefix of their counts); point i of a contour is the
-// state at step kpos + i of the closing walk, so step j of that walk lands at index (j - kpos) mod n.
+// k_trace_write: the points of every kept contour.  Ticket = write ticket of k_link (`pre` = per-frame prefix of their counts): a
+// lane replays its run of segments, 64 steps per round, into LDS, and the wave writes run after run with coalesced stores.
 __global__ __launch_bounds__(256) void k_trace_write(const uint8_t* __restrict__ nbr, DetectCfg cfg, int nframes,
                                                      const unsigned* __restrict__ pre, Counters* ctr,
-                                                     const ContourRec* __restrict__ contours, const CkptRec* __restrict__ ckpt,
+                                                     const ContourRec* __restrict__ contours, const WriteRec* __restrict__ wlist,
                                                      unsigned* __restrict__ points) {
     __shared__ unsigned sPre[kMaxFramesPerCall + 1];
     __shared__ unsigned sPts[4][64][64];
+    __shared__ unsigned short sStep[256 * 8];
     __shared__ unsigned sBase;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    build_step_table(sStep, tid, 256);
     for (int i = tid; i <= nframes; i += 256) sPre[i] = pre[i];
     __syncthreads();
     const unsigned total = sPre[nframes];
@@ -622,40 +868,52 @@ __global__ __launch_bounds__(256) void k_trace_write(const uint8_t* __restrict__
         __syncthreads();
         if (base >= total) break;                              // uniform
         const unsigned ticket = base + tid;
-        // every lane replays its segment into LDS (skewed so that the transposed read below is conflict-free) ...
         unsigned* dst = points;
-        int n = 1, idx0 = 0, cnt = 0;
+        const uint8_t* plane = nbr;
+        int n = 1, idx0 = 0, left = 0;
+        Walk w{0, 0, 0};
         if (ticket < total) {
             const int f = ticket_frame(sPre, nframes, ticket);
-            const unsigned q = ticket - sPre[f];
-            const CkptRec ck = ckpt[(size_t)f * cfg.cap_ckpt + q];
-            const ContourRec rec = contours[(size_t)f * cfg.cap_contours + ck.ci];
-            const uint8_t* plane = nbr + ((size_t)f * kScales + rec.scale) * nbr_plane_bytes(cfg.rows, pitch);
-            dst = points + (size_t)f * cfg.cap_points + rec.off;
-            n = (int)rec.n;
-            const int j0 = (int)(q - rec.ck_off) * kCkptStride;        // first walk step of this segment
-            cnt = min(kCkptStride, n - j0);
-            idx0 = j0 - rec.kpos;
-            if (idx0 < 0) idx0 += n;
-            Walk w{(int)(ck.state & 0xFFFu), (int)((ck.state >> 12) & 0xFFFu), (int)((ck.state >> 24) & 7u)};
-            for (int t = 0; t < cnt; t++) {
-                sPts[wave][lane][(t + lane) & 63] = ((unsigned)w.x & 0xFFFFu) | ((unsigned)w.y << 16);
-                walk_step(w, plane[nbr_index(w.x, w.y, pitch)]);
+            const WriteRec wr = wlist[(size_t)f * cfg.cap_write + (ticket - sPre[f])];
+            if (wr.ci != kNone) {
+                const ContourRec rec = contours[(size_t)f * cfg.cap_contours + wr.ci];
+                plane = nbr + ((size_t)f * kScales + rec.scale) * nbr_plane_bytes(cfg.rows, pitch);
+                dst = points + (size_t)f * cfg.cap_points + rec.off;
+                n = (int)rec.n;
+                idx0 = (int)wr.rel;
+                left = (int)(wr.cnt & 0xFFFFu);
+                w = Walk{(int)(wr.state & 0xFFFu), (int)((wr.state >> 12) & 0xFFFu), (int)((wr.state >> 24) & 7u)};
+                for (int t = (int)(wr.cnt >> 16); t > 0; t--) {    // the block begins this many steps into the segment
+                    const unsigned st = sStep[((unsigned)plane[nbr_index(w.x, w.y, pitch)] << 3) | (unsigned)w.s];
+                    w.x += (int)(st & 3u) - 1; w.y += (int)((st >> 2) & 3u) - 1; w.s = (int)((st >> 4) & 7u);
+                }
             }
         }
-        // ... and the wave writes segment after segment, 64 consecutive points (256 B) per store
         const unsigned long long dptr = (unsigned long long)dst;
-        for (int sgm = 0; sgm < 64; sgm++) {
-            const int scnt = __shfl(cnt, sgm);
-            if (scnt == 0) continue;                           // wave-uniform
-            const int sn = __shfl(n, sgm), sidx = __shfl(idx0, sgm);
-            const unsigned lo32 = __shfl((unsigned)dptr, sgm), hi32 = __shfl((unsigned)(dptr >> 32), sgm);
-            unsigned* sdst = (unsigned*)(((unsigned long long)hi32 << 32) | lo32);
-            if (lane < scnt) {
-                int o = sidx + lane;
-                if (o >= sn) o -= sn;
-                sdst[o] = sPts[wave][sgm][(lane + sgm) & 63];
+        while (__ballot(left > 0) != 0ull) {                    // wave-uniform
+            // every lane replays (up to) 64 steps of its run into LDS (skewed so that the transposed read below is conflict-free) ...
+            const int cnt = min(left, 64);
+            for (int t = 0; t < cnt; t++) {
+                sPts[wave][lane][(t + lane) & 63] = ((unsigned)w.x & 0xFFFFu) | ((unsigned)w.y << 16);
+                const unsigned st = sStep[((unsigned)plane[nbr_index(w.x, w.y, pitch)] << 3) | (unsigned)w.s];
+                w.x += (int)(st & 3u) - 1; w.y += (int)((st >> 2) & 3u) - 1; w.s = (int)((st >> 4) & 7u);
             }
+            // ... and the wave writes run after run, 64 consecutive points (256 B) per store
+            for (int sgm = 0; sgm < 64; sgm++) {
+                const int scnt = __shfl(cnt, sgm);
+                if (scnt == 0) continue;                       // wave-uniform
+                const int sn = __shfl(n, sgm), sidx = __shfl(idx0, sgm);
+                const unsigned lo32 = __shfl((unsigned)dptr, sgm), hi32 = __shfl((unsigned)(dptr >> 32), sgm);
+                unsigned* sdst = (unsigned*)(((unsigned long long)hi32 << 32) | lo32);
+                if (lane < scnt) {
+                    int o = sidx + lane;
+                    if (o >= sn) o -= sn;
+                    sdst[o] = sPts[wave][sgm][(lane + sgm) & 63];
+                }
+            }
+            idx0 += cnt;
+            if (idx0 >= n) idx0 -= n;
+            left -= cnt;
         }
     }
 }
@@ -1189,28 +1447,42 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
 // host launchers
 // ------------------------------------------------------------------------------------------------
 void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t frame_stride, size_t row_step, int nframes,
-                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, Counters* ctr) {
+                      uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, unsigned* nodeplane,
+                      Counters* ctr) {
     const unsigned total = (unsigned)((cfg.cols + TW - 1) / TW) * (unsigned)((cfg.rows + TH - 1) / TH) * (unsigned)nframes;
     const bool def = cfg.n_scales == 3 && cfg.win_r[0] == 1 && cfg.win_r[1] == 6 && cfg.win_r[2] == 11;
     if (def)
         hipLaunchKernelGGL(k_threshold<true>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg,
-                           starts, n_starts, ctr, nframes);
+                           starts, n_starts, nodeplane, ctr, nframes);
     else
         hipLaunchKernelGGL(k_threshold<false>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg,
-                           starts, n_starts, ctr, nframes);
+                           starts, n_starts, nodeplane, ctr, nframes);
 }
 void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre) {
     hipLaunchKernelGGL(k_prefix, dim3(1), dim3(256), 0, st, nframes, counts, cap, per_ticket, pre);
 }
-void launch_trace(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
-                  const unsigned* pre, Counters* ctr, ContourRec* contours, unsigned* n_contours,
-                  unsigned* n_points, CkptRec* ckpt, unsigned* n_ckpt, unsigned* lane_ckpt) {
-    hipLaunchKernelGGL(k_trace, dim3(nwaves), dim3(64), 0, st, nbr, cfg, nframes, starts, pre, ctr, contours, n_contours,
-                       n_points, ckpt, n_ckpt, lane_ckpt);
+void launch_seg(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
+                const unsigned* n_starts, const unsigned* nodeplane, const unsigned* pre, Counters* ctr, NodeRec* nodes) {
+    hipLaunchKernelGGL(k_seg, dim3(nwaves), dim3(64), 0, st, nbr, cfg, nframes, starts, n_starts, nodeplane, pre, ctr, nodes);
+}
+void launch_link(hipStream_t st, const DetectCfg& cfg, int nframes, const unsigned* n_starts, Counters* ctr, const NodeRec* nodes,
+                 unsigned* link_todo, ContourRec* contours, unsigned* n_contours, unsigned* n_points, WriteRec* wlist, unsigned* n_write) {
+    // ASLAM_LINK_LDS_NODES: nodes of a frame the LDS image holds (a test knob: 0 sends every frame through k_link_serial)
+    const char* env = std::getenv("ASLAM_LINK_LDS_NODES");
+    const unsigned lds_nodes = env ? std::min((unsigned)std::atoi(env), kLinkLdsNodes) : kLinkLdsNodes;
+    const size_t dyn = (size_t)kLinkLdsNodes * 10u + sizeof(LinkSlot) * kLinkSlots;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_link), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_link, dim3(nframes), dim3(kLinkThreads), dyn, st, cfg, n_starts, ctr, nodes, lds_nodes, link_todo, contours, n_contours,
+                       n_points, wlist, n_write);
+    hipLaunchKernelGGL(k_link_serial, dim3(nframes), dim3(512), 0, st, cfg, n_starts, ctr, nodes, link_todo, contours, n_contours, n_points, wlist, n_write);
 }
 void launch_trace_write(hipStream_t st, int nblocks, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* pre,
-                        Counters* ctr, const ContourRec* contours, const CkptRec* ckpt, unsigned* points) {
-    hipLaunchKernelGGL(k_trace_write, dim3(nblocks), dim3(256), 0, st, nbr, cfg, nframes, pre, ctr, contours, ckpt, points);
+                        Counters* ctr, const ContourRec* contours, const WriteRec* wlist, unsigned* points) {
+    hipLaunchKernelGGL(k_trace_write, dim3(nblocks), dim3(256), 0, st, nbr, cfg, nframes, pre, ctr, contours, wlist, points);
 }
 void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, int nframes, Counters* ctr, const ContourRec* contours,
                   const unsigned* n_contours, const unsigned* pre, const unsigned* points, CandRec* cands, unsigned* n_cand) {

@@ -72,8 +72,8 @@ int aslam_set_camera(aslam_ctx* ctx, const double K[9], const double* D, int nD)
 /* cv::aruco::DetectorParameters (OpenCV 3.2.0 field names and defaults).  The reference passes none (aruco_slam.cpp:313 uses
  * DetectorParameters::create()), so the defaults are what parity is checked with; this is the knob a maintainer gets
  * instead of the cv::Ptr.  Limits of the build, refused (never ignored) when exceeded: at most 3 threshold windows of 3..23
- * pixels (LDS tile halo, three mask planes), perspectiveRemovePixelPerCell 2..8, markerBorderBits 1, maxMarkerPerimeterRate
- * at most 4 (checkpoint storage per border walk).  doCornerRefinement (off in the reference) runs cv::cornerSubPix on the kept markers, one lane per corner,
+ * pixels (LDS tile halo, three mask planes), perspectiveRemovePixelPerCell 2..8, markerBorderBits 1, maxMarkerPerimeterRate x
+ * the larger side of the frame at most 65534 points (16-bit distances along a border).  doCornerRefinement (off in the reference) runs cv::cornerSubPix on the kept markers, one lane per corner,
  * with cornerRefinementWinSize 1..7. */
 typedef struct {
     int    adaptiveThreshWinSizeMin, adaptiveThreshWinSizeMax, adaptiveThreshWinSizeStep;

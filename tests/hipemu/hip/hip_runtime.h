@@ -240,7 +240,6 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = s
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 
-#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hipemu::g_dynshared);
 
 namespace hipemu {
 constexpr size_t kStackBytes = 96 * 1024;
@@ -336,6 +335,7 @@ template <class F> void run_grid(const char*, dim3 grid, dim3 block, F&& body) {
 }
 
 #define ASLAM_LDS_BARRIER() __syncthreads()
+#define ASLAM_DYN_LDS(name) alignas(16) static thread_local unsigned char name[160 * 1024]
 #define ASLAM_RCP_ESTIMATE(x) (1.0 / (x))
 #define ASLAM_WAVE_BCAST(v, src) __shfl(v, src)
 

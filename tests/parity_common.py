@@ -21,8 +21,8 @@ def nbr_from_binary(fg):
     return m
 
 
-def check_stages(ctx, slot, img, expect_ids=None, perim_rates=(0.03, 4.0), thresh_c=7.0, windows=(3, 13, 23)):
-    """threshold -> contours -> candidates -> detections of one staged frame against the oracle."""
+def check_contours(ctx, slot, img, perim_rates=(0.03, 4.0), thresh_c=7.0, windows=(3, 13, 23)):
+    """threshold -> contours of one staged frame against the oracle's sequential Suzuki-Abe scan: bit-identical"""
     rows, cols = img.shape
     lo, hi = int(perim_rates[0] * max(rows, cols)), int(perim_rates[1] * max(rows, cols))
     for s, k in enumerate(windows):
@@ -36,6 +36,11 @@ def check_stages(ctx, slot, img, expect_ids=None, perim_rates=(0.03, 4.0), thres
         assert np.array_equal(sizes[sel], gs), f"contour sizes differ at scale {s}"
         assert np.array_equal(keys[sel], gk), f"contour order differs at scale {s}"
         assert np.array_equal(opts, gp), f"contour points differ at scale {s}"
+
+
+def check_stages(ctx, slot, img, expect_ids=None, perim_rates=(0.03, 4.0), thresh_c=7.0, windows=(3, 13, 23)):
+    """threshold -> contours -> candidates -> detections of one staged frame against the oracle."""
+    check_contours(ctx, slot, img, perim_rates, thresh_c, windows)
     co, so, _, _ = orc.candidates(img, 0)
     cg, sg, _ = ctx.debug_candidates(slot, 0)
     assert np.array_equal(co, cg) and np.array_equal(so, sg), "quad candidates differ"

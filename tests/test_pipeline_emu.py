@@ -44,30 +44,57 @@ def test_detector_bgr_and_odd_size():
     assert np.array_equal(ids_o, ids_g) and np.array_equal(c_o, c_g)
 
 
-def test_contours_degenerate_images():
-    rows, cols = 64, 96
-    ctx = small_ctx(rows, cols, cap_starts_per_frame=1 << 15, cap_contours_per_frame=1 << 13, cap_points_per_frame=1 << 19)
-    ctx.set_camera(synth.camera_matrix(rows, cols, 100.0), np.zeros(5))
+def _spiral(rows, cols, step):
+    """a one-pixel-wide dark spiral on a bright ground: one very long border in a small area (many nodes on one cycle)"""
+    img = np.full((rows, cols), 220, np.uint8)
+    x0, y0, x1, y1 = 4, 4, cols - 5, rows - 5
+    while x1 - x0 > 2 * step and y1 - y0 > 2 * step:
+        img[y0, x0:x1 + 1] = 20
+        img[y0:y1 + 1, x1] = 20
+        img[y1, x0 + step:x1 + 1] = 20
+        img[y0 + step:y1 + 1, x0 + step] = 20
+        img[y0 + step, x0 + step:x1 - step + 1] = 20
+        x0 += step; y0 += step; x1 -= step; y1 -= step
+    return img
+
+
+@pytest.mark.parametrize("link", ["lds", "serial"])
+def test_contours_degenerate_images(link, monkeypatch):
+    """blocky noise, overlapping rectangles (axis-aligned borders: segments as long as the cut lattice allows), a spiral and a comb
+    (one border of thousands of points through hundreds of nodes): contours bit-identical to the sequential scan, through both
+    forms of the cycle resolution (k_link in LDS, k_link_serial through global memory)"""
+    if link == "serial":
+        monkeypatch.setenv("ASLAM_LINK_LDS_NODES", "0")
     rng = np.random.RandomState(0)
     checked = 0
-    for trial in range(8):
-        if trial % 2 == 0:
-            img = np.kron(rng.randint(0, 256, (rows // 4, cols // 4)), np.ones((4, 4))).astype(np.uint8)
-        else:
-            img = np.full((rows, cols), 200, np.uint8)
-            for _ in range(25):
-                x0, y0 = rng.randint(0, cols), rng.randint(0, rows)
-                img[y0:y0 + rng.randint(1, 30), x0:x0 + rng.randint(1, 30)] = rng.randint(0, 256)
-        ctx.stage_frames(img)
-        try:
-            ctx.run_staged(0, 1, with_ekf=False)
-            ctx.sync()
-        except capi.AslamError as e:
-            assert e.code == -4
-            continue
-        pc.check_stages(ctx, 0, img)
-        checked += 1
-    assert checked >= 4
+    for rows, cols, trials in ((64, 96, 6), (150, 200, 5)):
+        ctx = small_ctx(rows, cols, cap_starts_per_frame=1 << 16, cap_contours_per_frame=1 << 13, cap_points_per_frame=1 << 19)
+        ctx.set_camera(synth.camera_matrix(rows, cols, 100.0), np.zeros(5))
+        ctx.set_detector_params(maxMarkerPerimeterRate=40.0)       # keep the long borders: they are the point
+        for trial in range(trials):
+            if trial % 5 == 3:
+                img = _spiral(rows, cols, 4 + trial)
+            elif trial % 5 == 4:
+                img = np.full((rows, cols), 210, np.uint8)
+                img[10:rows - 10, 8:cols - 8:6] = 30                # a comb: teeth 1 px wide ...
+                img[10:14, 8:cols - 8] = 30                         # ... on one spine
+            elif trial % 2 == 0:
+                img = np.kron(rng.randint(0, 256, (rows // 4 + 1, cols // 4 + 1)), np.ones((4, 4))).astype(np.uint8)[:rows, :cols].copy()
+            else:
+                img = np.full((rows, cols), 200, np.uint8)
+                for _ in range(25):
+                    x0, y0 = rng.randint(0, cols), rng.randint(0, rows)
+                    img[y0:y0 + rng.randint(1, 30), x0:x0 + rng.randint(1, 30)] = rng.randint(0, 256)
+            ctx.stage_frames(img)
+            try:
+                ctx.run_staged(0, 1, with_ekf=False)
+                ctx.sync()
+            except capi.AslamError as e:
+                assert e.code == -4
+                continue
+            pc.check_contours(ctx, 0, img, perim_rates=(0.03, 40.0))
+            checked += 1
+    assert checked >= 8
 
 
 def test_empty_and_blank_frames():
