@@ -77,14 +77,14 @@ struct ContourRec {
 constexpr int kCutGrid = 64;      // power of two, divides the 64-pixel tile width of k_threshold
 constexpr unsigned kNodeCut = 0u, kNodeOuter = 1u, kNodeHole = 2u, kNodeInvalid = 3u;   // type field
 constexpr unsigned kNone = 0xFFFFFFFFu;
-// x[0:12) y[12:24) s[24:27) scale[27:29) type[29:31); bit 31 (NodeRec::state only): the candidate passes the run-top test
+// x[0:12) y[12:24) s[24:27) scale[27:29) type[29:31)
 __host__ __device__ inline unsigned pack_node(unsigned x, unsigned y, unsigned s, unsigned scale, unsigned type) {
     return x | (y << 12) | (s << 24) | (scale << 27) | (type << 29);
 }
 constexpr unsigned kNodeStateMask = 0x1FFFFFFFu;   // x, y, s, scale: identifies the state
 constexpr unsigned kNodePixelMask = 0x18FFFFFFu;   // x, y, scale: identifies the pixel
 struct NodeRec {                  // one segment: from this node's state to the next node's on the same border
-    unsigned state;               // pack_node | top << 31
+    unsigned state;               // pack_node
     unsigned nxt;                 // index of the next node in the frame's list, kNone when the walk was cut (longer than max_perim)
     unsigned len;                 // border-following steps to it
     int area;                     // shoelace partial sum over those steps

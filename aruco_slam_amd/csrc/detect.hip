@@ -392,35 +392,11 @@ __device__ __forceinline__ void walk_step(Walk& w, unsigned m) {
 }
 
 constexpr int kTraceChunk = 64;      // tickets per grab: one per lane
-constexpr int kRunLook = 8;          // pixels of the start candidate's run examined by the two tests below
 
-// A border's canonical start (the state the sequential raster scan starts it from) lies on the FIRST row of the border /
-// hole, so nothing of the same component may sit above the horizontal run it opens.  k_threshold's candidate test only
-// looks at the first pixel of that run; these look kRunLook pixels further (or to the run's end).  They are necessary
-// conditions of being canonical, so a candidate that fails them never competes for a border (k_link).
-//   outer: foreground run starting at (x, y) whose first pixel has W/NW/N/NE background: no later pixel of the run
-//          may have a N or NE foreground neighbour.
-//   hole : background run starting at (x, y) (W and N foreground): every pixel of the run must have N foreground (the
-//          background is 4-connected), and the run must end inside the image.
-__device__ __forceinline__ bool run_is_top_outer(const uint8_t* __restrict__ plane, int x, int y, int pitch, unsigned m0) {
-    unsigned m = m0;
-    for (int t = 1; t <= kRunLook; t++) {
-        if (!(m & 1u)) return true;                        // run ended (E is background)
-        m = plane[nbr_index(x + t, y, pitch)];
-        if (m & 0x06u) return false;                       // something above this run pixel
-    }
-    return true;
-}
-__device__ __forceinline__ bool run_is_top_hole(const uint8_t* __restrict__ plane, int x, int y, int pitch, int cols) {
-    unsigned m = plane[nbr_index(x, y, pitch)];            // the hole pixel itself (background, W and N foreground)
-    for (int t = 1; t <= kRunLook; t++) {
-        if (m & 1u) return true;                           // run ended (E is foreground)
-        if (x + t >= cols) return false;                   // open to the image frame: not a hole
-        m = plane[nbr_index(x + t, y, pitch)];
-        if (!(m & 0x04u)) return false;                    // the background continues upwards
-    }
-    return true;
-}
+// A border's canonical start - the state the sequential raster scan starts it from - is the start candidate of the border's own
+// type (outer / hole) with the smallest raster key on the cycle: the scan meets the border's topmost-leftmost pixel (outer) or the
+// hole's topmost-leftmost pixel (hole) first, and every other candidate of that type on the cycle lies on the same border, later
+// in raster order.  Candidates of the other type on the cycle (a hole-type state that hugs the outer background, say) never matter.
 
 // One border-following step as a table: (neighbour mask m, back direction s) -> dx + 1 | dy + 1 << 2 | new s << 4 | "this state is an
 // outer-type start candidate" << 7 | "... a hole-type one" << 8 | "the first examined neighbour s + 1 is background: a cut state where
@@ -443,8 +419,7 @@ __device__ __forceinline__ bool on_cut_grid(int x, int y) { return ((x & (kCutGr
 // k_seg: work-queue kernel, one lane per node (ticket = node of the whole call; `pre` = per-frame prefix of the node counts).
 // Every lane is a small state machine (idle -> walk -> idle); idle lanes are refilled from the queue with one atomic per 64
 // tickets.  A lane walks from its node's state until it stands on the next node of the border, finds that node's index through the
-// node plane, and records (next, steps, shoelace partial sum).  (Stopping only at candidates that pass the run-top test would
-// shorten the node cycles, but the test is up to eight dependent loads in the middle of a wave's walk loop: measured slower.)
+// node plane, and records (next, steps, shoelace partial sum).
 __global__ __launch_bounds__(64) void k_seg(const uint8_t* __restrict__ nbr, DetectCfg cfg, int nframes,
                                             const unsigned* __restrict__ starts, const unsigned* __restrict__ n_starts,
                                             const unsigned* __restrict__ nodeplane,
@@ -457,7 +432,7 @@ __global__ __launch_bounds__(64) void k_seg(const uint8_t* __restrict__ nbr, Det
     for (int i = lane; i <= nframes; i += 64) sPre[i] = pre[i];
     __syncthreads();
     const unsigned total = sPre[nframes];
-    const int pitch = cfg.pitch, cols = cfg.cols;
+    const int pitch = cfg.pitch;
     const size_t plane_bytes = nbr_plane_bytes(cfg.rows, pitch);
 
     int mode = 0;                       // 0 idle, 1 walking
@@ -495,10 +470,7 @@ __global__ __launch_bounds__(64) void k_seg(const uint8_t* __restrict__ nbr, Det
                     const unsigned sc = (e >> 27) & 3u;
                     plane = nbr + ((size_t)f * kScales + sc) * plane_bytes;
                     idplane = nodeplane + ((size_t)f * kScales + sc) * plane_bytes;
-                    bool top = false;
-                    if (type == kNodeOuter) top = run_is_top_outer(plane, x, y, pitch, plane[nbr_index(x, y, pitch)]);
-                    else if (type == kNodeHole) top = run_is_top_hole(plane, x + 1, y, pitch, cols);
-                    state0 = e | (top ? 0x80000000u : 0u);
+                    state0 = e;
                     w = Walk{x, y, (int)((e >> 24) & 7u)};
                     area = 0;
                     n = 0;
@@ -553,7 +525,7 @@ __global__ __launch_bounds__(64) void k_seg(const uint8_t* __restrict__ nbr, Det
 //   2. ranking: every node learns its distance to the leader along the border ((distance, pointer) pairs, doubling until every
 //      pointer stands on the leader); the leader's own distance is the border's length n;
 //   3. borders with min_perim <= n <= max_perim get a slot; all their nodes add their shoelace sums into it and the start
-//      candidates that pass the run-top test their keys (LDS atomics);
+//      candidates their keys, per type (LDS atomics);
 //   4. the first candidate of the border's own type (outer / hole, by the sign of the area) - the start the sequential scan would
 //      have used - emits the contour;
 //   5. every node of an emitted border writes the tickets of the 64-point blocks of the contour that begin inside its segment.
@@ -663,8 +635,8 @@ __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsi
         const NodeRec r = gn[i];
         atomicAdd(&sSlot[sl].area, r.area);
         const unsigned type = (r.state >> 29) & 3u;
-        if ((r.state >> 31) && type == kNodeOuter) atomicMin(&sSlot[sl].kmin_outer, node_key(r.state, cols));
-        if ((r.state >> 31) && type == kNodeHole) atomicMin(&sSlot[sl].kmin_hole, node_key(r.state, cols));
+        if (type == kNodeOuter) atomicMin(&sSlot[sl].kmin_outer, node_key(r.state, cols));
+        if (type == kNodeHole) atomicMin(&sSlot[sl].kmin_hole, node_key(r.state, cols));
     }
     __syncthreads();
     // ---- 4. the canonical start emits the contour ----
@@ -673,7 +645,7 @@ __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsi
         if (sl < 0) continue;
         const NodeRec r = gn[i];
         const unsigned type = (r.state >> 29) & 3u;
-        if (!(r.state >> 31) || (type != kNodeOuter && type != kNodeHole)) continue;
+        if (type != kNodeOuter && type != kNodeHole) continue;
         const LinkSlot s = sSlot[sl];
         const bool is_hole = s.area > 0;                       // outer borders run counter-clockwise on screen
         if (type != (is_hole ? kNodeHole : kNodeOuter)) continue;
@@ -717,11 +689,11 @@ __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsi
 }
 
 // k_link_serial: the frames k_link left (link_todo), through global memory, one workgroup per frame.  One lane per node; only
-// start candidates that pass the run-top test do anything: such a lane hops from node to node along its border, one hop per round,
-// while the idle lanes of its wave are refilled from the frame's ticket counter.  A candidate with a smaller key that also passes
-// the test belongs to a lane that will do (or hand on) this border: stop.  The lane that gets back to its own node has the
-// smallest surviving key of the border; it emits the contour from the first candidate of the border's own type, then goes
-// round once more and cuts the border into write tickets: runs of whole segments of at least kWriteChunk points each.
+// start candidates do anything: such a lane hops from node to node along its border, one hop per round, while the idle lanes of
+// its wave are refilled from the frame's ticket counter.  A candidate with a smaller key belongs to a lane that will do (or hand
+// on) this border: stop.  The lane that gets back to its own node has the smallest key of the border; it emits the contour from
+// the first candidate of the border's own type, then goes round once more and cuts the border into write tickets: runs of whole
+// segments of at least kWriteChunk points each.
 __global__ __launch_bounds__(512) void k_link_serial(DetectCfg cfg, const unsigned* __restrict__ n_starts, Counters* ctr,
                                                      const NodeRec* __restrict__ nodes, const unsigned* __restrict__ link_todo,
                                                      ContourRec* __restrict__ contours, unsigned* __restrict__ n_contours,
@@ -765,7 +737,7 @@ __global__ __launch_bounds__(512) void k_link_serial(DetectCfg cfg, const unsign
                 self = lo + rank;
                 cur = fn[self];
                 const unsigned type = (cur.state >> 29) & 3u;
-                if (cur.state != kNone && (type == kNodeOuter || type == kNodeHole) && (cur.state >> 31)) {
+                if (cur.state != kNone && (type == kNodeOuter || type == kNodeHole)) {
                     key0 = node_key(cur.state, cols);
                     kmin_outer = type == kNodeOuter ? key0 : INT_MAX;
                     kmin_hole = type == kNodeHole ? key0 : INT_MAX;
@@ -814,7 +786,7 @@ __global__ __launch_bounds__(512) void k_link_serial(DetectCfg cfg, const unsign
                 const unsigned t2 = (cur.state >> 29) & 3u;
                 if (t2 == kNodeOuter || t2 == kNodeHole) {
                     const int key = node_key(cur.state, cols);
-                    if (key < key0 && (cur.state >> 31)) mode = 0;  // a smaller canonical candidate owns this border
+                    if (key < key0) mode = 0;                       // the candidate with the smaller key owns this border
                     if (t2 == kNodeHole) { if (key < kmin_hole) { kmin_hole = key; kpos_hole = n; } }
                     else if (key < kmin_outer) { kmin_outer = key; kpos_outer = n; }
                 }

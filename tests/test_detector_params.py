@@ -52,7 +52,7 @@ def test_parameters_change_the_result():
 
 
 @pytest.mark.parametrize("bad", [dict(adaptiveThreshWinSizeMax=33), dict(perspectiveRemovePixelPerCell=12), dict(markerBorderBits=2),
-                                 dict(doCornerRefinement=1, cornerRefinementWinSize=9), dict(maxMarkerPerimeterRate=6.0), dict(polygonalApproxAccuracyRate=0.0)])
+                                 dict(doCornerRefinement=1, cornerRefinementWinSize=9), dict(maxMarkerPerimeterRate=2000.0), dict(polygonalApproxAccuracyRate=0.0)])
 def test_compiled_in_or_invalid_values_are_refused(bad):
     ctx = capi.Context(max_rows=64, max_cols=64, max_batch=1, persistent_waves=4, max_landmarks=16)
     with pytest.raises(capi.AslamError):

@@ -59,15 +59,22 @@ def test_detector_bgr_input_and_distortion():
     pc.check_poses(ids_g, c_g, rv, tv, K, D)
 
 
-def test_contours_on_degenerate_images():
-    """random / blocky / thin-line images: every border the sequential Suzuki scan finds, in its order, point for point"""
+@pytest.mark.parametrize("link", ["lds", "serial"])
+def test_contours_on_degenerate_images(link, monkeypatch):
+    """random / blocky / thin-line / smooth-blob images, a spiral and a comb (one border of thousands of points through hundreds of
+    nodes): every border the sequential Suzuki scan finds, in its order, point for point - through both forms of the cycle
+    resolution (k_link in LDS; k_link_serial, which pure noise needs anyway: more nodes than the LDS image holds)"""
+    from scipy.ndimage import gaussian_filter
+    from test_pipeline_emu import _spiral
+    if link == "serial":
+        monkeypatch.setenv("ASLAM_LINK_LDS_NODES", "0")
     rows, cols = 240, 320
     ctx = capi.Context(max_rows=rows, max_cols=cols, max_batch=1, max_landmarks=4, cap_contours_per_frame=1 << 15,
                        cap_points_per_frame=1 << 21, cap_starts_per_frame=1 << 17)
     ctx.set_camera(synth.camera_matrix(rows, cols, 200.0), np.zeros(5))
     rng = np.random.RandomState(7)
-    for trial in range(12):
-        kind = trial % 4
+    for trial in range(21):
+        kind = trial % 7
         if kind == 0:
             img = rng.randint(0, 256, (rows, cols)).astype(np.uint8)
         elif kind == 1:
@@ -75,11 +82,22 @@ def test_contours_on_degenerate_images():
         elif kind == 2:
             img = np.kron(rng.randint(0, 256, (rows // 3, cols // 4)), np.ones((3, 4))).astype(np.uint8)[:rows, :cols]
             img = np.ascontiguousarray(np.pad(img, ((0, rows - img.shape[0]), (0, cols - img.shape[1])), mode="edge"))
-        else:
+        elif kind == 3:
             img = np.full((rows, cols), 210, np.uint8)
             for _ in range(60):
                 x0, y0 = rng.randint(0, cols), rng.randint(0, rows)
                 img[y0:y0 + rng.randint(1, 40), x0:x0 + rng.randint(1, 40)] = rng.randint(0, 256)
+        elif kind == 4:
+            img = _spiral(rows, cols, 3 + trial // 7)
+        elif kind == 5:
+            img = np.full((rows, cols), 210, np.uint8)
+            img[10:rows - 10, 8:cols - 8:5 + trial // 7] = 30
+            img[10:14, 8:cols - 8] = 30
+        else:
+            g = gaussian_filter(rng.standard_normal((rows, cols)), 2.0 + trial // 7)
+            img = np.clip(128 + 900 * g, 0, 255).astype(np.uint8)           # smooth blobs: curved borders, touching the frame
+        long_borders = kind >= 4
+        ctx.set_detector_params(maxMarkerPerimeterRate=40.0 if long_borders else 4.0)
         ctx.stage_frames(img)
         try:
             ctx.run_staged(0, 1, with_ekf=False)
@@ -87,7 +105,10 @@ def test_contours_on_degenerate_images():
         except capi.AslamError as e:
             assert e.code == -4            # candidate-list capacity on pure-noise input is reported, never silent
             continue
-        pc.check_stages(ctx, 0, img)
+        if long_borders:
+            pc.check_contours(ctx, 0, img, perim_rates=(0.03, 40.0))
+        else:
+            pc.check_stages(ctx, 0, img)
 
 
 def test_slam_sequence_cfg1_literal_oracle():
