@@ -335,12 +335,8 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
     const int chunk = chunk_env > 0 ? std::min(chunk_env, max_frames_per_call()) : max_frames_per_call();
     for (int f0 = first; f0 < first + count; f0 += chunk) {
         const int nf = std::min(chunk, first + count - f0);
-        HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, kCounterHeads * sizeof(unsigned), st));   // queue heads and work count; the overflow mask is sticky
-        HIP_TRY(c, hipMemsetAsync(c->d_nstarts + f0, 0, sizeof(unsigned) * nf, st));
-        HIP_TRY(c, hipMemsetAsync(c->d_ncontours + f0, 0, sizeof(unsigned) * nf, st));
-        HIP_TRY(c, hipMemsetAsync(c->d_npoints + f0, 0, sizeof(unsigned) * nf, st));
-        HIP_TRY(c, hipMemsetAsync(c->d_nwrite + f0, 0, sizeof(unsigned) * nf, st));
-        HIP_TRY(c, hipMemsetAsync(c->d_ncand + f0, 0, sizeof(unsigned) * nf, st));
+        // queue heads, work count and the per-frame list sizes of these frames, in one launch (the overflow mask is sticky)
+        launch_clear_counts(st, nf, c->d_ctr, c->d_nstarts + f0, c->d_ncontours + f0, c->d_npoints + f0, c->d_nwrite + f0, c->d_ncand + f0);
         const uint8_t* in = c->d_in + (size_t)f0 * c->in_frame_bytes;
         uint8_t* nbr = c->d_nbr + (size_t)f0 * kScales * nbr_plane_bytes(g.rows, g.pitch);
         const uint8_t* gray = alias_gray ? in : c->d_gray + (size_t)f0 * frame_px;

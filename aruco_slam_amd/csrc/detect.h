@@ -7,6 +7,8 @@ namespace aslam {
 void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t frame_stride, size_t row_step, int nframes,
                       uint8_t* gray, uint8_t* nbr, const DetectCfg& cfg, unsigned* starts, unsigned* n_starts, unsigned* nodeplane,
                       Counters* ctr);
+void launch_clear_counts(hipStream_t st, int nframes, Counters* ctr, unsigned* n_starts, unsigned* n_contours, unsigned* n_points, unsigned* n_write,
+                         unsigned* n_cand);
 void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre);
 void launch_seg(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
                 const unsigned* n_starts, const unsigned* nodeplane, const unsigned* pre, Counters* ctr, NodeRec* nodes);

@@ -335,6 +335,13 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
 #endif
 }
 
+// k_clear_counts: the work-queue heads and the per-frame list sizes of a detection call (one launch instead of six fills)
+__global__ __launch_bounds__(256) void k_clear_counts(int nframes, Counters* ctr, unsigned* a0, unsigned* a1, unsigned* a2, unsigned* a3, unsigned* a4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < kCounterHeads) reinterpret_cast<unsigned*>(ctr)[i] = 0u;
+    if (i < nframes) { a0[i] = 0u; a1[i] = 0u; a2[i] = 0u; a3[i] = 0u; a4[i] = 0u; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_prefix : per-frame work counts -> ticket ranges of the two work-queue kernels (one workgroup)
 // ------------------------------------------------------------------------------------------------
@@ -894,6 +901,8 @@ __global__ __launch_bounds__(256) void k_trace_write(const uint8_t* __restrict__
 // k_quads : approxPolyDP (closed) + quad tests, one WAVEFRONT per contour
 // ------------------------------------------------------------------------------------------------
 struct IPt { int x, y; };
+constexpr int kQuadLdsPts = 2048;     // 8 KB per wavefront
+constexpr int kQuadGrab = 4;          // contours per grab of k_quads
 __device__ __forceinline__ IPt ld_pt(const unsigned* p, int i) {
     unsigned v = p[i];
     return IPt{(int)(short)(v & 0xFFFFu), (int)(short)(v >> 16)};
@@ -912,7 +921,21 @@ __device__ __forceinline__ void wave_first_max(double& d, int& pos) {
 // Returns the number of vertices (<= 8) written to out, or -1 when the result cannot have 4 vertices.
 // Early exit rule: every stack slice yields at least one vertex and the final clean-up removes at most
 // floor(count/2) of them, so new_count + stack > 8 can never end at 4.  All lanes run the same control flow.
-__device__ int approx_poly_closed_wave(const unsigned* __restrict__ src, int count, double eps, IPt* out, int lane) {
+#ifdef ASLAM_QUADS_STAMPS
+#define QST(i) do { const long long t_ = clock64(); qst[i] += t_ - qlast; qlast = t_; } while (0)
+#else
+#define QST(i) do { } while (0)
+#endif
+// kLds: the points come from the wavefront's LDS copy `spts` (plain DS reads; a generic pointer into LDS is never formed), else from
+// global memory
+template <bool kLds>
+__device__ int approx_poly_closed_body(const unsigned* __restrict__ gsrc, const unsigned* spts, int count, double eps, IPt* out, int lane
+#ifdef ASLAM_QUADS_STAMPS
+                                       , long long* qst, long long& qlast
+#endif
+                                       ) {
+    auto P = [&](int i) -> unsigned { return kLds ? spts[i] : gsrc[i]; };
+    auto ld = [&](int i) -> IPt { const unsigned v = P(i); return IPt{(int)(short)(v & 0xFFFFu), (int)(short)(v >> 16)}; };
     struct Range { int start, end; };
     // wave-uniform work arrays: one copy per wavefront in LDS (every lane stores the same value) instead of per-lane scratch
     __shared__ Range stack[10];
@@ -927,18 +950,32 @@ __device__ int approx_poly_closed_wave(const unsigned* __restrict__ src, int cou
     right_slice.start = 0;
     for (int it = 0; it < 3; it++) {
         pos = (pos + right_slice.start) % count;             // index of this iteration's start point
-        start_pt = ld_pt(src, pos);
+        start_pt = ld(pos);
         double best = 0.0;
         int bestj = 0x7fffffff;
-        for (int j = 1 + lane; j < count; j += 64) {
-            int idx = pos + j;
-            if (idx >= count) idx -= count;
-            pt = ld_pt(src, idx);
-            double dx = pt.x - start_pt.x, dy = pt.y - start_pt.y;
-            double dist = dx * dx + dy * dy;
-            if (dist > best) { best = dist; bestj = j; }
+        // (four loads in flight per lane: the points were written by another kernel, every load is a miss of this CU's caches)
+        for (int j0 = 1 + lane; j0 < count; j0 += 4 * 64) {
+            unsigned v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 64 * u;
+                int idx = pos + j;
+                if (idx >= count) idx -= count;
+                v[u] = j < count ? P(idx) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + 64 * u;
+                if (j < count) {
+                    const double dx = (int)(short)(v[u] & 0xFFFFu) - start_pt.x, dy = (int)(short)(v[u] >> 16) - start_pt.y;
+                    const double dist = dx * dx + dy * dy;
+                    if (dist > best) { best = dist; bestj = j; }
+                }
+            }
         }
+        QST(0);
         wave_first_max(best, bestj);
+        QST(1);
         if (best > 0.0) right_slice.start = bestj;          // unchanged when no point is farther than 0 (as in the scan)
         le_eps = best <= eps;
         // the scan reads `count` points in all, so `pos` is back at the start index
@@ -953,8 +990,8 @@ __device__ int approx_poly_closed_wave(const unsigned* __restrict__ src, int cou
     }
     while (top > 0) {
         slice = stack[--top];
-        end_pt = ld_pt(src, slice.end);
-        start_pt = ld_pt(src, slice.start);
+        end_pt = ld(slice.end);
+        start_pt = ld(slice.start);
         int first = slice.start + 1;
         if (first >= count) first = 0;
         if (first != slice.end) {
@@ -963,14 +1000,29 @@ __device__ int approx_poly_closed_wave(const unsigned* __restrict__ src, int cou
             double dx = end_pt.x - start_pt.x, dy = end_pt.y - start_pt.y;
             double best = 0.0;
             int bestt = 0x7fffffff;
-            for (int t = lane; t < len; t += 64) {
-                int idx = first + t;
-                if (idx >= count) idx -= count;
-                pt = ld_pt(src, idx);
-                double dist = fabs((pt.y - start_pt.y) * dx - (pt.x - start_pt.x) * dy);
-                if (dist > best) { best = dist; bestt = t; }
+            QST(2);
+            for (int t0 = lane; t0 < len; t0 += 4 * 64) {
+                unsigned v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + 64 * u;
+                    int idx = first + t;
+                    if (idx >= count) idx -= count;
+                    v[u] = t < len ? P(idx) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + 64 * u;
+                    if (t < len) {
+                        const int px = (int)(short)(v[u] & 0xFFFFu), py = (int)(short)(v[u] >> 16);
+                        const double dist = fabs((py - start_pt.y) * dx - (px - start_pt.x) * dy);
+                        if (dist > best) { best = dist; bestt = t; }
+                    }
+                }
             }
+            QST(3);
             wave_first_max(best, bestt);
+            QST(1);
             if (best > 0.0) { int idx = first + bestt; if (idx >= count) idx -= count; right_slice.start = idx; }
             le_eps = best * best <= eps * (dx * dx + dy * dy);
         } else {
@@ -987,6 +1039,7 @@ __device__ int approx_poly_closed_wave(const unsigned* __restrict__ src, int cou
         if (new_count + top > 8) return -1;
     }
     // final clean-up
+    QST(2);
     int count2 = new_count;
     pos = count2 - 1;
     start_pt = dst[pos]; if (++pos >= count2) pos = 0;
@@ -1010,7 +1063,41 @@ __device__ int approx_poly_closed_wave(const unsigned* __restrict__ src, int cou
         pt = end_pt;
     }
     for (int i = 0; i < new_count; i++) out[i] = dst[i];
+    QST(4);
     return new_count;
+}
+
+// Returns the number of vertices (<= 8) written to out, or -1 when the result cannot have 4 vertices (see the body).
+// The points were written by another kernel: every access would be a miss of this CU's caches, and the passes are chains of
+// dependent accesses (slice end points, then the slice).  A contour of up to kQuadLdsPts points is read once, all loads in flight
+// together, into LDS.
+__device__ int approx_poly_closed_wave(const unsigned* __restrict__ src, int count, double eps, IPt* out, int lane
+#ifdef ASLAM_QUADS_STAMPS
+                                       , long long* qst, long long& qlast
+#endif
+                                       ) {
+    __shared__ unsigned spts[kQuadLdsPts];
+    if (count <= kQuadLdsPts) {                                 // wave-uniform
+        __syncthreads();                                        // (the workgroup is this one wavefront) the previous contour's reads are done
+        for (int i0 = lane; i0 < count; i0 += 8 * 64) {
+            unsigned v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[min(i0 + 64 * u, count - 1)];      // (unconditional: a guarded load is a branch with its own wait)
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (i0 + 64 * u < count) spts[i0 + 64 * u] = v[u];
+        }
+        __syncthreads();
+#ifdef ASLAM_QUADS_STAMPS
+        return approx_poly_closed_body<true>(src, spts, count, eps, out, lane, qst, qlast);
+#else
+        return approx_poly_closed_body<true>(src, spts, count, eps, out, lane);
+#endif
+    }
+#ifdef ASLAM_QUADS_STAMPS
+    return approx_poly_closed_body<false>(src, spts, count, eps, out, lane, qst, qlast);
+#else
+    return approx_poly_closed_body<false>(src, spts, count, eps, out, lane);
+#endif
 }
 
 __device__ __forceinline__ bool quad_is_convex(const IPt* p) {
@@ -1040,17 +1127,44 @@ __global__ __launch_bounds__(64) void k_quads(DetectCfg cfg, int nframes, Counte
     for (int i = lane; i <= nframes; i += 64) sPre[i] = pre[i];
     __syncthreads();
     const unsigned total = sPre[nframes];
+#ifdef ASLAM_QUADS_STAMPS
+    long long qst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long qlast = clock64();
+    int qn = 0;
+#endif
+    // kQuadGrab consecutive contours per grab: one atomic and one round of record loads (all in flight together) for the lot -
+    // unless there are too few contours to go round (a single frame): then one at a time, on as many waves as possible
+    const unsigned grab = total > 2u * (unsigned)kQuadGrab * gridDim.x ? (unsigned)kQuadGrab : 1u;
     for (;;) {
-        unsigned ticket = 0;
-        if (lane == 0) ticket = atomicAdd(&ctr->q_quads, 1u);
-        ticket = __shfl(ticket, 0);
-        if (ticket >= total) break;
-        const int f = ticket_frame(sPre, nframes, ticket);
-        const ContourRec rec = contours[(size_t)f * cfg.cap_contours + (ticket - sPre[f])];
-        if (rec.n > 0) {                                       // wave-uniform
+        unsigned base = 0;
+        QST(5);
+        if (lane == 0) base = atomicAdd(&ctr->q_quads, grab);
+        base = __shfl(base, 0);
+        if (base >= total) break;
+        const unsigned limit = min(total, base + grab);
+        ContourRec recs[kQuadGrab];
+        int fs[kQuadGrab];
+#pragma unroll
+        for (int u = 0; u < kQuadGrab; u++) {
+            const unsigned t = min(base + (unsigned)u, total - 1u);
+            fs[u] = ticket_frame(sPre, nframes, t);
+            recs[u] = contours[(size_t)fs[u] * cfg.cap_contours + (t - sPre[fs[u]])];
+        }
+        QST(6);
+#pragma unroll
+        for (int u = 0; u < kQuadGrab; u++) {
+        const ContourRec rec = recs[u];
+        const int f = fs[u];
+        if (base + (unsigned)u < limit && rec.n > 0) {         // wave-uniform
             __shared__ IPt q[8];                                // wave-uniform, like the work arrays of approx_poly_closed_wave
+#ifdef ASLAM_QUADS_STAMPS
+            qn++;
+            int nv = approx_poly_closed_wave(points + (size_t)f * cfg.cap_points + rec.off, (int)rec.n,
+                                             (double)rec.n * cfg.approx_rate, q, lane, qst, qlast);
+#else
             int nv = approx_poly_closed_wave(points + (size_t)f * cfg.cap_points + rec.off, (int)rec.n,
                                              (double)rec.n * cfg.approx_rate, q, lane);
+#endif
             bool ok = nv == 4 && quad_is_convex(q);
             if (ok) {
                 int mx = max(cfg.cols, cfg.rows);
@@ -1079,8 +1193,15 @@ __global__ __launch_bounds__(64) void k_quads(DetectCfg cfg, int nframes, Counte
                     atomicOr(&ctr->overflow, (unsigned)kOvfCands);
                 }
             }
+            QST(7);
+        }
         }
     }
+#ifdef ASLAM_QUADS_STAMPS
+    if (lane == 0 && blockIdx.x < 3 && nframes >= 32)
+        printf("quads wave %d: %d contours; cycles: initial loops %lld, reductions %lld, slice overhead %lld, slice loops %lld, clean-up %lld, ticket %lld, record %lld, tests+emit %lld\n",
+               (int)blockIdx.x, qn, qst[0], qst[1], qst[2], qst[3], qst[4], qst[5], qst[6], qst[7]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1429,6 +1550,11 @@ void launch_threshold(hipStream_t st, const uint8_t* in, int channels, size_t fr
     else
         hipLaunchKernelGGL(k_threshold<false>, dim3((total + 7u) / 8u * 8u), dim3(256), 0, st, in, channels, frame_stride, row_step, gray, nbr, cfg,
                            starts, n_starts, nodeplane, ctr, nframes);
+}
+void launch_clear_counts(hipStream_t st, int nframes, Counters* ctr, unsigned* n_starts, unsigned* n_contours, unsigned* n_points, unsigned* n_write,
+                         unsigned* n_cand) {
+    hipLaunchKernelGGL(k_clear_counts, dim3((std::max(nframes, kCounterHeads) + 255) / 256), dim3(256), 0, st, nframes, ctr, n_starts, n_contours, n_points,
+                       n_write, n_cand);
 }
 void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre) {
     hipLaunchKernelGGL(k_prefix, dim3(1), dim3(256), 0, st, nframes, counts, cap, per_ticket, pre);

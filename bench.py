@@ -583,12 +583,14 @@ def main():
         run = None
         # the same sizes off the fast path: the reference's own detector configuration on the headline scene, and a
         # world whose visible set slides (with the scene's detector profile and with the defaults)
-        for label, cname, det, qual in (("cfg2_reference_defaults", "cfg2", "reference", False),
-                                        ("cfg2_sliding", "cfg2_sliding", "scene", True),
-                                        ("cfg2_sliding_reference_defaults", "cfg2_sliding", "reference", False)):
+        # ... and the headline frames through detection + pose alone (the EKF side bounds the headline; this is what the detector does)
+        for label, cname, det, qual, ekf_on in (("cfg2_reference_defaults", "cfg2", "reference", False, True),
+                                                ("cfg2_sliding", "cfg2_sliding", "scene", True, True),
+                                                ("cfg2_sliding_reference_defaults", "cfg2_sliding", "reference", False, True),
+                                                ("cfg2_detect_pose_only", "cfg2", "scene", True, False)):
             try:
                 lapn = synth.make_world(synth.CONFIGS[cname]).lap_length()
-                rx, runx = run_config(mods, args, cname, 8, 2, lapn, True, 0, local_rank, 1, 0, want_gather=False, detector=det, qualify=qual)
+                rx, runx = run_config(mods, args, cname, 8, 2, lapn, ekf_on, 0, local_rank, 1, 0, want_gather=False, detector=det, qualify=qual)
                 rx["unit"] = "frames/s"
                 runx["ctx"].close()
                 extra[label] = rx
