@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256) void k_trace_write(const uint8_t* __restrict__
 // k_quads : approxPolyDP (closed) + quad tests, one WAVEFRONT per contour
 // ------------------------------------------------------------------------------------------------
 struct IPt { int x, y; };
-constexpr int kQuadLdsPts = 2048;     // 8 KB per wavefront
+constexpr int kQuadLdsPts = 1536;     // 6 KB per wavefront (with the rest: 15 wavefronts per CU)
 constexpr int kQuadGrab = 4;          // contours per grab of k_quads
 __device__ __forceinline__ IPt ld_pt(const unsigned* p, int i) {
     unsigned v = p[i];
@@ -1321,6 +1321,7 @@ __global__ __launch_bounds__(1024) void k_assemble(DetectCfg cfg, Counters* ctr,
 // ------------------------------------------------------------------------------------------------
 constexpr int kWarpMax = kDictMaxCells * kCellPx;   // 72
 
+constexpr int kWarpUnroll = 25;        // pixels of the warped marker image per lane and round (a 7 x 7-cell marker at 8 px per cell: 49 per lane, two rounds)
 __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, const uint8_t* __restrict__ gray,
                                                  FinalCand* __restrict__ finals, const IdentWork* __restrict__ work,
                                                  const unsigned long long* __restrict__ dict_codes) {
@@ -1330,6 +1331,8 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
     __shared__ uint8_t img[kWarpMax * kWarpMax];
     __shared__ int hist[256];
     __shared__ int sDecision[2];        // [0]: 0 = otsu, 1 = all zero bits, 2 = all one bits ; [1]: otsu threshold
+    __shared__ double sOtsuA[256], sOtsuB[256], sMu;   // per bin: p_i, i p_i; then q1 (-1: skipped), mu1
+    __shared__ int sOtsuRange[2];
     const int lane = threadIdx.x & 63;
     const int rows = cfg.rows, cols = cfg.cols;
     const int ms = cfg.marker_size, bb = cfg.border_bits;
@@ -1337,9 +1340,18 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
     const int cell = cfg.cell_px;
     const int S = nc * cell;                    // warped image side
     const unsigned n_work = ctr->n_ident;
+#ifdef ASLAM_IDENT_STAMPS
+    long long ist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long ilast = clock64();
+    int inum = 0;
+#define IST(i) do { const long long t_ = clock64(); ist[i] += t_ - ilast; ilast = t_; } while (0)
+#else
+#define IST(i) do { } while (0)
+#endif
 
     for (;;) {
         unsigned wi = 0;
+        IST(7);
         if (lane == 0) wi = atomicAdd(&ctr->q_ident, 1u);
         wi = __shfl(wi, 0);
         if (wi >= n_work) break;
@@ -1348,6 +1360,7 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
         const uint8_t* gimg = gray + (size_t)wk.frame * rows * cols;
 
         for (int i = lane; i < 256; i += 64) hist[i] = 0;
+        IST(0);
         {
             // cv::getPerspectiveTransform(corners -> (0,0),(S-1,0),(S-1,S-1),(0,S-1)): the 8 x 8 elimination with partial pivoting, one
             // matrix element per lane (row er = lane / 8, column ec = lane % 8; every lane of a row carries the row's right-hand side).
@@ -1366,32 +1379,37 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
                 ea = k == 0 ? (double)sx : k == 1 ? (double)sy : k == 2 ? 1.0 : 0.0;
             }
             double eb = dst;
+            // rows are exchanged through LDS (the workgroup is one wavefront): per column one write of the matrix, then broadcast reads of
+            // the pivot column, the pivot row and the right-hand side - a quarter of the LDS-pipe operations of lane-to-lane shuffles
             for (int col = 0; col < 8; col++) {
+                __syncthreads();                                     // the previous column's reads are done
+                sA[er][ec] = ea;
+                if (ec == 0) sB[er] = eb;
+                __syncthreads();
                 int piv = col;
-                double best = fabs(__shfl(ea, col * 8 + col));
+                double best = fabs(sA[col][col]);
                 for (int r = col + 1; r < 8; r++) {
-                    const double v = fabs(__shfl(ea, r * 8 + col));
+                    const double v = fabs(sA[r][col]);
                     if (v > best) { best = v; piv = r; }
                 }
-                if (piv != col) {                                    // uniform
-                    const double fromPiv = __shfl(ea, piv * 8 + ec), fromCol = __shfl(ea, col * 8 + ec);
-                    const double bPiv = __shfl(eb, piv * 8), bCol = __shfl(eb, col * 8);
-                    if (er == col) { ea = fromPiv; eb = bPiv; }
-                    else if (er == piv) { ea = fromCol; eb = bCol; }
-                }
-                const double pv = __shfl(ea, col * 8 + col);
-                const double mine = __shfl(ea, er * 8 + col);
-                const double rowc = __shfl(ea, col * 8 + ec), brow = __shfl(eb, col * 8);
+                // after the exchange row `col` holds what row `piv` held, and the other way round
+                if (er == col) { ea = sA[piv][ec]; eb = sB[piv]; }
+                else if (er == piv) { ea = sA[col][ec]; eb = sB[col]; }
+                const double pv = sA[piv][col];
+                const double mine = er == col ? pv : er == piv ? sA[col][col] : sA[er][col];
+                const double rowc = sA[piv][ec], brow = sB[piv];
                 if (er > col) {
                     const double fct = mine / pv;
                     if (ec >= col) ea -= fct * rowc;
                     eb -= fct * brow;
                 }
             }
+            __syncthreads();
             sA[er][ec] = ea;
             if (ec == 0) sB[er] = eb;
         }
         __syncthreads();
+        IST(1);
         if (lane == 0) {
             double x[8];
             for (int i = 7; i >= 0; i--) {
@@ -1419,56 +1437,124 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
         }
         __syncthreads();
 
+        IST(2);
         // warpPerspective(INTER_NEAREST), histogram, inner-region moments
         const int lo = cell / 2, hi = S - cell / 2;
         long long sum = 0, sq = 0;
-        for (int p = lane; p < S * S; p += 64) {
-            int y = p / S, x = p - y * S;
-            double X0 = sM[1] * y + sM[2], Y0 = sM[4] * y + sM[5], W0 = sM[7] * y + sM[8];
-            double W = W0 + sM[6] * x;
-            W = W ? 1. / W : 0;
-            double fX = fmax((double)INT_MIN, fmin((double)INT_MAX, (X0 + sM[0] * x) * W));
-            double fY = fmax((double)INT_MIN, fmin((double)INT_MAX, (Y0 + sM[3] * x) * W));
-            long long X = (long long)rint(fX), Y = (long long)rint(fY);
-            int v = 0;
-            if (X >= 0 && X < cols && Y >= 0 && Y < rows) v = gimg[(size_t)Y * cols + X];
-            img[p] = (uint8_t)v;
-            atomicAdd(&hist[v], 1);
-            if (x >= lo && x < hi && y >= lo && y < hi) { sum += v; sq += v * v; }
+        // (kWarpUnroll pixels per round: their gray loads are issued together, at clamped addresses - a guarded load is a branch with
+        //  its own wait, and the loads of a lane's ~50 pixels would queue up behind each other)
+        // pixel p = lane + 64 k of the warped image; (x, y) advanced without divisions, once for the addresses and once for the use
+        const int step_y = 64 / S, step_x = 64 - step_y * S;
+        int py = lane / S, px = lane - py * S;
+        int qy = py, qx = px;
+        for (int p0 = lane; p0 < S * S; p0 += 64 * kWarpUnroll) {
+            int vv[kWarpUnroll];                                    // gray value, -1 outside the frame
+#pragma unroll
+            for (int u = 0; u < kWarpUnroll; u++) {
+                const int x = px, y = min(py, S - 1);                // (beyond the image: any valid pixel, the value is not used)
+                px += step_x; py += step_y;
+                if (px >= S) { px -= S; py++; }
+                double X0 = sM[1] * y + sM[2], Y0 = sM[4] * y + sM[5], W0 = sM[7] * y + sM[8];
+                double W = W0 + sM[6] * x;
+                W = W ? 1. / W : 0;
+                double fX = fmax((double)INT_MIN, fmin((double)INT_MAX, (X0 + sM[0] * x) * W));
+                double fY = fmax((double)INT_MIN, fmin((double)INT_MAX, (Y0 + sM[3] * x) * W));
+                const int X = (int)rint(fX), Y = (int)rint(fY);      // clamped to the int range above: the 32-bit conversion is exact
+                const bool inside = X >= 0 && X < cols && Y >= 0 && Y < rows;
+                const int g = gimg[inside ? (size_t)Y * cols + X : (size_t)0];
+                vv[u] = inside ? g : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < kWarpUnroll; u++) {
+                const int p = p0 + 64 * u;
+                const int x = qx, y = qy;
+                qx += step_x; qy += step_y;
+                if (qx >= S) { qx -= S; qy++; }
+                if (p < S * S) {
+                    const int v = max(vv[u], 0);
+                    img[p] = (uint8_t)v;
+                    atomicAdd(&hist[v], 1);
+                    if (x >= lo && x < hi && y >= lo && y < hi) { sum += v; sq += v * v; }
+                }
+            }
         }
+        IST(3);
         for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); sq += __shfl_down(sq, o); }
         __syncthreads();
-        if (lane == 0) {
-            const double scale = 1.0 / ((double)(hi - lo) * (hi - lo));
-            const double mean = sum * scale;
-            const double var = fmax(sq * scale - mean * mean, 0.);
-            const double stddev = sqrt(var);
-            if (stddev < cfg.min_otsu_std) {
-                sDecision[0] = mean > 127 ? 2 : 1;
-                sDecision[1] = 0;
-            } else {
-                // getThreshVal_Otsu_8u over the whole warped image
-                const int N = S * S;
-                double mu = 0, sc = 1. / N;
-                for (int i = 0; i < 256; i++) mu += i * (double)hist[i];
-                mu *= sc;
-                double mu1 = 0, q1 = 0, max_sigma = 0, max_val = 0;
-                for (int i = 0; i < 256; i++) {
-                    double p_i = hist[i] * sc;
-                    mu1 *= q1;
-                    q1 += p_i;
-                    double q2 = 1. - q1;
-                    if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) continue;
-                    mu1 = (mu1 + i * p_i) / q1;
-                    double mu2 = (mu - q1 * mu1) / q2;
-                    double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
-                    if (sigma > max_sigma) { max_sigma = sigma; max_val = i; }
+        // getThreshVal_Otsu_8u over the whole warped image.  Only (q1, mu1) are carried from bin to bin: one lane runs that recurrence
+        // - every operation of the sequential loop, bins before the first and after the last occupied one leave nothing behind - and all
+        // lanes then evaluate sigma for their bins from the stored (q1, mu1); first maximum as in the scan.
+        {
+            const int N = S * S;
+            const double sc = 1. / N;
+            long long isum = 0;                                     // sum of i * hist[i]: integers, exact in any order
+            unsigned long long occupied[4];
+            for (int k = 0; k < 4; k++) {
+                const int i = lane + 64 * k;
+                const int h = hist[i];
+                const double p_i = h * sc;
+                sOtsuA[i] = p_i;
+                sOtsuB[i] = i * p_i;
+                isum += (long long)i * h;
+                occupied[k] = __ballot(h != 0);
+            }
+            for (int o = 32; o > 0; o >>= 1) isum += __shfl_down(isum, o);
+            __syncthreads();
+            if (lane == 0) {
+                const double scale = 1.0 / ((double)(hi - lo) * (hi - lo));
+                const double mean = sum * scale;
+                const double var = fmax(sq * scale - mean * mean, 0.);
+                const double stddev = sqrt(var);
+                if (stddev < cfg.min_otsu_std) {
+                    sDecision[0] = mean > 127 ? 2 : 1;
+                    sDecision[1] = 0;
+                } else {
+                    sDecision[0] = 0;
+                    int first = 256, last = -1;
+                    for (int k = 0; k < 4; k++)
+                        if (occupied[k]) { first = min(first, 64 * k + __ffsll((long long)occupied[k]) - 1); last = 64 * k + 63 - __clzll((long long)occupied[k]); }
+                    sOtsuRange[0] = first; sOtsuRange[1] = last;
+                    sMu = (double)isum * sc;
+                    double mu1 = 0, q1 = 0;
+                    for (int i = first; i <= last; i++) {
+                        const double p_i = sOtsuA[i], ip_i = sOtsuB[i];
+                        mu1 *= q1;
+                        q1 += p_i;
+                        const double q2 = 1. - q1;
+                        if (fmin(q1, q2) < FLT_EPSILON || fmax(q1, q2) > 1. - FLT_EPSILON) {
+                            sOtsuA[i] = -1.;                         // no sigma for this bin
+                        } else {
+                            mu1 = (mu1 + ip_i) / q1;
+                            sOtsuA[i] = q1;
+                            sOtsuB[i] = mu1;
+                        }
+                    }
                 }
-                sDecision[0] = 0;
-                sDecision[1] = (int)max_val;
+            }
+            __syncthreads();
+            if (sDecision[0] == 0) {                                 // uniform
+                const int first = sOtsuRange[0], last = sOtsuRange[1];
+                const double mu = sMu;
+                double best = 0.0;
+                int besti = 0x7fffffff;
+                for (int k = 0; k < 4; k++) {
+                    const int i = lane + 64 * k;
+                    if (i >= first && i <= last) {
+                        const double q1 = sOtsuA[i], mu1 = sOtsuB[i];
+                        if (q1 >= 0.) {
+                            const double q2 = 1. - q1;
+                            const double mu2 = (mu - q1 * mu1) / q2;
+                            const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+                            if (sigma > best) { best = sigma; besti = i; }
+                        }
+                    }
+                }
+                wave_first_max(best, besti);
+                if (lane == 0) sDecision[1] = best > 0.0 ? besti : 0;
             }
         }
         __syncthreads();
+        IST(4);
         // cell votes: up to 81 cells, lanes take cells lane and lane + 64
         unsigned long long bitsLo = 0, bitsHi = 0;       // cell index c -> bit c (lo) / c - 64 (hi)
         {
@@ -1496,6 +1582,7 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
             int c = cy * nc + cx;
             return c < 64 ? (int)((bitsLo >> c) & 1ull) : (int)((bitsHi >> (c - 64)) & 1ull);
         };
+        IST(5);
         // _getBorderErrors
         int borderErr = 0;
         for (int y = 0; y < nc; y++)
@@ -1533,7 +1620,16 @@ __global__ __launch_bounds__(64) void k_identify(DetectCfg cfg, Counters* ctr, c
             fc->id = id;
         }
         __syncthreads();
+        IST(6);
+#ifdef ASLAM_IDENT_STAMPS
+        inum++;
+#endif
     }
+#ifdef ASLAM_IDENT_STAMPS
+    if (lane == 0 && blockIdx.x < 3 && n_work > 1000)
+        printf("identify wave %d: %d candidates; cycles: fetch %lld, elimination %lld, back-substitution %lld, warp %lld, moments+otsu %lld, votes %lld, border+dictionary %lld, ticket %lld\n",
+               (int)blockIdx.x, inum, ist[0], ist[1], ist[2], ist[3], ist[4], ist[5], ist[6], ist[7]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
