@@ -30,9 +30,9 @@ namespace {
 constexpr int kWinWidenFrames = 16;     // a window of at least this many frames is not widened to the next image size (64 -> 128 -> 192)
 constexpr int kWinChainFrames = 8;      // frames per chain kernel of a window (its log is replayed meanwhile); <= kWinPieceMax
 
-enum ProfId { P_THRESH, P_TRACE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
+enum ProfId { P_THRESH, P_SEG, P_LINK, P_WRITE, P_QUADS, P_ASSEMBLE, P_IDENTIFY, P_POSE, P_EKF_PLAN, P_EKF_GATHER, P_EKF_SMALL,
               P_EKF_T, P_EKF_UPDATE, P_EKF_MID, P_EKF_APPLY, P_EKF_MID64, P_EKF_WIN_CHAIN, P_EKF_WIN_SCAN, P_EKF_WIN_FLUSH, P_EKF_WIN_NEXT, P_COUNT };
-const char* kProfNames[P_COUNT] = {"k_threshold", "k_trace", "k_quads", "k_assemble", "k_identify", "k_pose",
+const char* kProfNames[P_COUNT] = {"k_threshold", "k_seg", "k_link", "k_trace_write", "k_quads", "k_assemble", "k_identify", "k_pose",
                                    "k_ekf_plan", "k_ekf_gather", "k_ekf_small", "k_ekf_T", "k_ekf_update_mfma", "k_ekf_mid", "k_ekf_apply",
                                    "k_ekf_mid64", "k_ekf_win_step", "k_ekf_win_drain", "k_ekf_win_flush", "k_ekf_win_next"};
 
@@ -348,14 +348,18 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
                          alias_gray ? nullptr : c->d_gray + (size_t)f0 * frame_px, nbr, g, starts, c->d_nstarts + f0,
                          c->d_nodeplane + (size_t)f0 * kScales * nbr_plane_bytes(g.rows, g.pitch), c->d_ctr);
         prof_end(c);
-        prof_begin(c, P_TRACE, st);
+        prof_begin(c, P_SEG, st);
         launch_prefix(st, nf, c->d_nstarts + f0, g.cap_starts, 1u, c->d_pre_trace);
         NodeRec* nodes = c->d_nodes + (size_t)f0 * g.cap_starts;
         WriteRec* wlist = c->d_wlist + (size_t)f0 * g.cap_write;
         launch_seg(st, c->nwaves, nbr, g, nf, starts, c->d_nstarts + f0, c->d_nodeplane + (size_t)f0 * kScales * nbr_plane_bytes(g.rows, g.pitch),
                    c->d_pre_trace, c->d_ctr, nodes);
+        prof_end(c);
+        prof_begin(c, P_LINK, st);
         launch_link(st, g, nf, c->d_nstarts + f0, c->d_ctr, nodes, c->d_link_todo + f0, contours, c->d_ncontours + f0, c->d_npoints + f0, wlist,
                     c->d_nwrite + f0);
+        prof_end(c);
+        prof_begin(c, P_WRITE, st);
         launch_prefix(st, nf, c->d_nwrite + f0, g.cap_write, 1u, c->d_pre_write);
         launch_trace_write(st, std::max(64, c->nwaves / 4), nbr, g, nf, c->d_pre_write, c->d_ctr, contours, wlist, points);
         prof_end(c);

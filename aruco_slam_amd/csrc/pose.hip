@@ -12,26 +12,44 @@
 namespace aslam {
 
 // ---- small dense helpers (fp64, per lane) --------------------------------------------------------------
-template <int N> __device__ void solve_pp(double* A, double* b, double* x) {   // Gaussian elimination, partial pivoting
+template <int N> __device__ __forceinline__ void solve_pp(double* A, double* b, double* x) {   // Gaussian elimination, partial pivoting
+    // Every index below is a compile-time constant once the loops are unrolled - the pivot row is exchanged by selects over the
+    // candidate rows, not through a run-time index - so that A, b and x live in registers (a run-time row index sends the whole
+    // matrix to scratch memory, and the LM iterations of k_pose are one long chain through it).
+#pragma unroll
     for (int col = 0; col < N; col++) {
         int piv = col;
         double best = fabs(A[col * N + col]);
+#pragma unroll
         for (int r = col + 1; r < N; r++) {
             double v = fabs(A[r * N + col]);
             if (v > best) { best = v; piv = r; }
         }
-        if (piv != col) {
-            for (int c = 0; c < N; c++) { double t = A[piv * N + c]; A[piv * N + c] = A[col * N + c]; A[col * N + c] = t; }
-            double t = b[piv]; b[piv] = b[col]; b[col] = t;
+#pragma unroll
+        for (int r = col + 1; r < N; r++) {
+            const bool sw = piv == r;                            // true for at most one r
+#pragma unroll
+            for (int c = 0; c < N; c++) {
+                const double u = A[col * N + c], w = A[r * N + c];
+                A[col * N + c] = sw ? w : u;
+                A[r * N + c] = sw ? u : w;
+            }
+            const double u = b[col], w = b[r];
+            b[col] = sw ? w : u;
+            b[r] = sw ? u : w;
         }
+#pragma unroll
         for (int r = col + 1; r < N; r++) {
             double f = A[r * N + col] / A[col * N + col];
+#pragma unroll
             for (int c = col; c < N; c++) A[r * N + c] -= f * A[col * N + c];
             b[r] -= f * b[col];
         }
     }
+#pragma unroll
     for (int i = N - 1; i >= 0; i--) {
         double s = b[i];
+#pragma unroll
         for (int c = i + 1; c < N; c++) s -= A[i * N + c] * x[c];
         x[i] = s / A[i * N + i];
     }
@@ -395,26 +413,35 @@ __global__ __launch_bounds__(128) void k_pose(const FinalCand* __restrict__ fina
     const FinalCand* fin = finals + (size_t)f * kCandMax;
     const int nF = (int)min(n_final[f], (unsigned)kCandMax);
 
-    if (tid == 0) {
-        int k = 0;
-        for (int i = 0; i < nF; i++)
-            if (fin[i].id >= 0) {
-                if (k < kMarkerMax) {
-                    sId[k] = fin[i].id;
-                    // _identifyOneCandidate: std::rotate(begin, begin + 4 - rot, end) -> new[j] = old[(j + 4 - rot) % 4]
-                    const int rot = fin[i].pad[0];
-                    for (int j = 0; j < 4; j++) {
-                        const int sidx = (j + 4 - rot) & 3;
-                        sC[k][2 * j] = fin[i].c[2 * sidx];
-                        sC[k][2 * j + 1] = fin[i].c[2 * sidx + 1];
-                    }
-                    k++;
-                } else {
-                    atomicOr(&ctr->overflow, (unsigned)kOvfMarkers);
+    // the identified candidates, in candidate order (an ordered compaction: ballot ranks inside a wave, the first wave's count
+    // for the second - one thread walking the list would pay one dependent global load per candidate)
+    __shared__ int sCnt[2];
+    int kbase = 0;
+    for (int i0 = 0; i0 < nF; i0 += 128) {                     // uniform
+        const int i = i0 + tid;
+        const int id = i < nF ? fin[i].id : -1;
+        const unsigned long long has = __ballot(id >= 0);
+        if ((tid & 63) == 0) sCnt[tid >> 6] = __popcll(has);
+        __syncthreads();
+        const int k = kbase + (tid >= 64 ? sCnt[0] : 0) + __popcll(has & ((1ull << (tid & 63)) - 1ull));
+        if (id >= 0) {
+            if (k < kMarkerMax) {
+                sId[k] = id;
+                // _identifyOneCandidate: std::rotate(begin, begin + 4 - rot, end) -> new[j] = old[(j + 4 - rot) % 4]
+                const int rot = fin[i].pad[0];
+                for (int j = 0; j < 4; j++) {
+                    const int sidx = (j + 4 - rot) & 3;
+                    sC[k][2 * j] = fin[i].c[2 * sidx];
+                    sC[k][2 * j + 1] = fin[i].c[2 * sidx + 1];
                 }
+            } else {
+                atomicOr(&ctr->overflow, (unsigned)kOvfMarkers);
             }
-        sN = k;
+        }
+        kbase += sCnt[0] + sCnt[1];
+        __syncthreads();                                        // before the next chunk's counts
     }
+    if (tid == 0) sN = min(kbase, kMarkerMax);
     for (int i = tid; i < kMarkerMax; i += 128) sRem[i] = 0;
     __syncthreads();
     const int n = sN;

@@ -170,7 +170,7 @@ def test_sliding_visibility_world(detector):
 @pytest.mark.gpu
 @pytest.mark.parametrize("waves", [256, 4096, 8192])
 def test_results_do_not_depend_on_the_number_of_work_queue_waves(waves):
-    """the work-queue kernels (k_trace, k_quads, k_identify) hand out work dynamically: any wave count gives the same frames"""
+    """the work-queue kernels (k_seg, k_trace_write, k_quads, k_identify) hand out work dynamically: any wave count gives the same frames"""
     cfg = synth.CONFIGS["cfg2"]
     stats, ctx, o = pc.run_slam_sequence(cfg, 48, batch=24, literal=False, ctx_kwargs=dict(persistent_waves=waves))
     assert stats["max_sigma"] < pc.TIGHT
