@@ -133,9 +133,11 @@ def load_pmc(cfg_name, with_ekf):
     bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts wide coalesced reads at 1/2,
     MI355X_MICROARCH.md §HBM), averaged over the launches of the profiled command (the same launch shapes as the timed steps)"""
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True)
+    # (second pass: a detect + pose only run of a config takes the detection kernels' figures from the config's full profile)
+    for f, need_exact in [(f, True) for f in files] + [(f, False) for f in files]:
         js = json.load(open(f))
-        if js.get("config", "cfg2") == cfg_name and js.get("ekf", True) == with_ekf:
+        if js.get("config", "cfg2") == cfg_name and (js.get("ekf", True) == with_ekf or (not need_exact and not with_ekf)):
             per_launch = {k: int((2.0 * v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024)
                           for k, v in js["kernels"].items() if k.startswith("k_") and k != "k_render"}      # (k_render is the input generator)
             return os.path.basename(f), per_launch
