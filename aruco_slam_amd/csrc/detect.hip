@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         const int ty = u / (TW / 4), tx4 = (u - ty * (TW / 4)) * 4;
         const int gy = y0 + ty;
         const bool row_on_grid = (gy & (kCutGrid - 1)) == 0;
+        // which of the thread's four pixels lie on the cut lattice (x0 is a multiple of kCutGrid); pixels beyond the frame are never foreground
+        const unsigned grid4 = row_on_grid ? 15u : ((tx4 & (kCutGrid - 1)) == 0 ? 1u : 0u);
+        static_assert(kCutGrid % 4 == 0, "a thread's four pixels start on a multiple of 4");
         unsigned out[kScales] = {0, 0, 0};
         unsigned emit = 0;                                          // bit 4 s + j: pixel j of scale s may carry nodes
 #pragma unroll
@@ -267,10 +270,10 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                     const unsigned idx = ((six[0] >> j) & 7u) | (((six[1] >> j) & 7u) << 3) | (((six[2] >> j) & 7u) << 6);
                     const unsigned t = sLut[idx];
                     out[s] |= (t & 0xFFu) << (8 * j);
-                    const unsigned on_grid = (row_on_grid || ((tx4 + j) & (kCutGrid - 1)) == 0) ? 1u : 0u;    // x0 is a multiple of kCutGrid
-                    emit |= (((t >> 9) | ((t >> 8) & on_grid)) & 1u) << (4 * s + j);
+                    emit |= ((t >> 9) & 1u) << (4 * s + j);       // start candidate
                 }
             }
+            emit |= (((six[1] >> 1) & grid4) & 15u) << (4 * s);     // foreground pixels on the cut lattice (bits 1..4 of the centre row)
         }
         for (unsigned rest = emit; rest; rest &= rest - 1u) {       // rare: a few pixels per tile
             const int bit = __ffs((int)rest) - 1, s = bit >> 2, j = bit & 3;
