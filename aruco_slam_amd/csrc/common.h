@@ -54,9 +54,9 @@ struct DetectCfg {
 };
 
 struct Counters {                 // per-call scalars (work-queue heads, overflow mask); list sizes live in per-frame arrays
-    unsigned q_trace, q_quads, n_ident, q_ident, q_write, q_link, overflow, pad;
+    unsigned q_trace, q_quads, n_ident, q_ident, q_write, overflow, pad[2];
 };
-constexpr int kCounterHeads = 6;  // leading words reset before every detection call (the overflow mask is sticky)
+constexpr int kCounterHeads = 5;  // leading words reset before every detection call (the overflow mask is sticky)
 
 struct ContourRec {
     unsigned frame, scale, key, n, off;

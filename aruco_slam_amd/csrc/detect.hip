@@ -3,12 +3,15 @@
 //
 //   k_threshold  BGR->gray + 3x adaptiveThreshold(MEAN_C, BINARY_INV, win 3/13/23, C=7) in ONE pass over the
 //                frame: LDS tile with a 12-px halo, LDS integral image, exact integer box means; emits, per
-//                scale, an 8-neighbour occupancy byte per pixel and the list of border start candidates.
-//   k_trace      Suzuki-Abe border following (findContours RETR_LIST/CHAIN_APPROX_NONE) without a sequential
-//                raster scan: every border is a cycle of (pixel, back-direction) states; a lane walks the cycle
-//                from each local start candidate and only the canonical one (the state the sequential scan would
-//                have started from) emits the contour.  Work-queue kernel, one lane per candidate.
-//   k_quads      approxPolyDP + the quad tests of _findMarkerContours, one lane per contour.
+//                scale, an 8-neighbour occupancy byte per pixel and the list of border nodes (start candidates + cut states).
+//   k_seg, k_link, k_trace_write
+//                Suzuki-Abe border following (findContours RETR_LIST/CHAIN_APPROX_NONE) without a sequential raster scan and
+//                without long walks: every border is a cycle of (pixel, back-direction) states; k_threshold lists the nodes that
+//                cut the cycles into short segments (common.h), k_seg walks each segment (one lane per node), k_link resolves the
+//                node cycles of a frame by pointer jumping in LDS - the canonical start (the state the sequential scan would
+//                have started from) emits the contour - and k_trace_write replays the segments of the kept contours, 64 points
+//                per lane.
+//   k_quads      approxPolyDP + the quad tests of _findMarkerContours, one wavefront per contour.
 //   k_assemble   candidate ordering (scale, reverse discovery), _reorderCandidatesCorners,
 //                _filterTooCloseCandidates; one workgroup per frame.
 //   k_identify   _extractBits (perspective warp, Otsu) + border check + Dictionary::identify; one wavefront
@@ -34,6 +37,9 @@ __device__ __forceinline__ int first_outer(unsigned m) { return (m & 1u) ? 0 : (
 // first foreground neighbour clockwise from E: SE, S, SW, W, NW, N, NE = highest set bit among bits 7..1
 __device__ __forceinline__ int first_hole(unsigned m) { return 31 - __clz((int)(m & 0xFEu)); }
 
+
+// top bit of every byte of x that is zero (exact: no borrow between bytes)
+__device__ __forceinline__ unsigned byte_is_zero(unsigned x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }
 
 // ------------------------------------------------------------------------------------------------
 // k_threshold
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
     __shared__ unsigned I[LH + 1][LW + 1];
     __shared__ unsigned long long sRow[kScales][TH + 2];     // threshold decisions of ring row by, columns x0 - 1 .. x0 + 62 (bit = column)
     __shared__ unsigned long long sRing[kScales][2];         // ... of columns x0 + 63 and x0 + 64 (bit = ring row)
-    __shared__ unsigned short sLut[512];
+    __shared__ unsigned sLutRow[3][64];            // six bits of the row above / at / below four pixels -> its bits of their four neighbour masks
     __shared__ unsigned sStart[kBlockStarts];      // pack_node(x, y, s, scale, type)
     __shared__ unsigned sNStart, sBase;
 
@@ -225,25 +231,26 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                 if (lane == 0) sRing[s][wave] = col;
             }
         }
-        // neighbourhood table: index = N3 | C3 << 3 | S3 << 6 (three pixels west..east of the rows above / at / below) ->
-        // bits 0..7 the neighbour mask (bit d = neighbour in direction d is foreground; 0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE),
-        // bit 8 the pixel is foreground, bit 9 it carries a start candidate of the raster scan: outer type (W/NW/N/NE background, not
-        // isolated) or hole type (E background and NE foreground: the pixel left of a background pixel whose W and N are foreground)
-        for (int i = tid; i < 512; i += 256) {
-            const unsigned n3 = i & 7u, c3 = (i >> 3) & 7u, s3 = (unsigned)i >> 6;
-            const unsigned m = ((c3 >> 2) & 1u) | (((n3 >> 2) & 1u) << 1) | (((n3 >> 1) & 1u) << 2) | ((n3 & 1u) << 3) | ((c3 & 1u) << 4) |
-                               ((s3 & 1u) << 5) | (((s3 >> 1) & 1u) << 6) | (((s3 >> 2) & 1u) << 7);
-            const unsigned fg = (c3 >> 1) & 1u;
-            const bool outer = fg && m != 0 && (m & 0x1Eu) == 0;
-            const bool hole = fg && (m & 3u) == 2u;
-            sLut[i] = (unsigned short)(m | (fg ? 0x100u : 0u) | ((outer || hole) ? 0x200u : 0u));
+        // neighbour masks of four pixels of a row at once: bit d of a mask = the neighbour in direction d is foreground (0=E 1=NE 2=N
+        // 3=NW 4=W 5=SW 6=S 7=SE).  Bits b0..b5 of a bit row are the columns x - 1 .. x + 4 of the four pixels x .. x + 3: the row above
+        // gives NW / N / NE, the pixels' own row W / E, the row below SW / S / SE - one table per row, indexed by the six bits, holding
+        // that row's share of the four mask bytes.
+        if (tid < 3 * 64) {
+            const unsigned r = tid >> 6, v = tid & 63u;
+            unsigned w = 0;
+            for (unsigned j = 0; j < 4; j++) {
+                const unsigned a = (v >> j) & 1u, b = (v >> (j + 1)) & 1u, c = (v >> (j + 2)) & 1u;   // columns x_j - 1, x_j, x_j + 1
+                const unsigned m = r == 0 ? (c << 1) | (b << 2) | (a << 3) : r == 1 ? c | (a << 4) : (a << 5) | (b << 6) | (c << 7);
+                w |= m << (8 * j);
+            }
+            sLutRow[r][v] = w;
         }
     }
     __syncthreads();
     THR_STAMP(3);
 
     // 4. neighbour masks and border nodes (common.h: start candidates + cut states; staged in LDS, one reservation per tile in the
-    //    frame's list): a thread takes four pixels of a row; six consecutive bits of the three bit rows around them index the table above
+    //    frame's list): a thread takes four pixels of a row; six consecutive bits of each of the three bit rows around them index the tables above
     for (int u = tid; u < TH * TW / 4; u += 256) {
         const int ty = u / (TW / 4), tx4 = (u - ty * (TW / 4)) * 4;
         const int gy = y0 + ty;
@@ -263,16 +270,14 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                 if (tx4 == TW - 4) v |= ((unsigned)(sRing[s][0] >> by) & 1u) << 4 | ((unsigned)(sRing[s][1] >> by) & 1u) << 5;
                 six[r] = v;
             }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int gx = x0 + tx4 + j;
-                if (gx < cols && gy < rows) {
-                    const unsigned idx = ((six[0] >> j) & 7u) | (((six[1] >> j) & 7u) << 3) | (((six[2] >> j) & 7u) << 6);
-                    const unsigned t = sLut[idx];
-                    out[s] |= (t & 0xFFu) << (8 * j);
-                    emit |= ((t >> 9) & 1u) << (4 * s + j);       // start candidate
-                }
-            }
+            const unsigned m4 = sLutRow[0][six[0]] | sLutRow[1][six[1]] | sLutRow[2][six[2]];   // the four masks, one byte each
+            out[s] = m4;
+            // start candidates, byte-parallel (flags in the top bit of each byte): foreground and either outer type - not isolated, NE / N / NW
+            // / W background - or hole type - E background, NE foreground
+            const unsigned fgb = (((six[1] >> 1) & 15u) * 0x00204081u & 0x01010101u) << 7;
+            const unsigned hole_x = (m4 & 0x03030303u) ^ 0x02020202u;
+            const unsigned cand = fgb & ((byte_is_zero(m4 & 0x1E1E1E1Eu) & ~byte_is_zero(m4)) | byte_is_zero(hole_x));
+            emit |= (((cand >> 7) | (cand >> 14) | (cand >> 21) | (cand >> 28)) & 15u) << (4 * s);
             emit |= (((six[1] >> 1) & grid4) & 15u) << (4 * s);     // foreground pixels on the cut lattice (bits 1..4 of the centre row)
         }
         for (unsigned rest = emit; rest; rest &= rest - 1u) {       // rare: a few pixels per tile
