@@ -129,6 +129,7 @@ _SIGS = {
     "aslam_comm_gather_maps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "aslam_comm_destroy": (C.c_int, [C.c_void_p]),
     "aslam_debug_get_nbr": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _u8p]),
+    "aslam_debug_get_frame_counts": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]),
     "aslam_debug_get_contours": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, _ip, _ip, _ip, _ip, _llp]),
     "aslam_debug_get_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _ip, _fp, _ip, _ip]),
     "aslam_debug_inject_observations": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _ip, _ip, _dp, _dp]),
@@ -463,6 +464,12 @@ class Context:
         out = np.zeros((rows, cols), np.uint8)
         self._ck(self.lib.aslam_debug_get_nbr(self.h, int(slot), int(scale), _ptr(out, _u8p)))
         return out
+
+    def debug_frame_counts(self, slot):
+        """list sizes of one slot after its last detection pass"""
+        out = (C.c_uint * 6)()
+        self._ck(self.lib.aslam_debug_get_frame_counts(self.h, int(slot), out))
+        return dict(zip(("nodes", "contours", "points", "write_tickets", "quad_candidates", "serial_link"), [int(v) for v in out]))
 
     def debug_contours(self, slot, scale, max_contours=20000, max_points=4_000_000):
         n = C.c_int(); tot = C.c_longlong()

@@ -1899,6 +1899,13 @@ int aslam_debug_inject_observations(aslam_ctx* c, int slot, int n, const int* id
     return ASLAM_OK;
 }
 
+int aslam_debug_get_frame_counts(aslam_ctx* c, int slot, unsigned* out /* 6 */) {
+    if (!c || !out || slot < 0 || slot >= c->max_batch) return ASLAM_E_INVALID;
+    const unsigned* src[6] = {c->d_nstarts, c->d_ncontours, c->d_npoints, c->d_nwrite, c->d_ncand, c->d_link_todo};
+    for (int i = 0; i < 6; i++)
+        if (hipMemcpy(out + i, src[i] + slot, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return ASLAM_E_HIP;
+    return ASLAM_OK;
+}
 int aslam_debug_get_counters(aslam_ctx* c, unsigned* out) {
     return hipMemcpy(out, c->d_ctr, 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }

@@ -549,11 +549,13 @@ __device__ __forceinline__ int node_key(unsigned state, int cols) {
     return (int)((state >> 12) & 0xFFFu) * cols + (int)(state & 0xFFFu) + (((state >> 29) & 3u) == kNodeHole ? 1 : 0);
 }
 constexpr int kLinkThreads = 1024;
-constexpr unsigned kLinkLdsNodes = 12288;        // x 10 B = 120 KB
-constexpr unsigned kLinkSlots = 1024;            // x 32 B = 32 KB
-struct LinkSlot {
-    int area, kmin_outer, kmin_hole;
-    unsigned n, ci, wbase, pos_canon, pad;
+constexpr unsigned kLinkLdsNodes = 32000;        // x (4 B + 1 bit) = 129 KB; node indices < 0x8000
+constexpr unsigned kLinkSlots = 1536;            // x 16 B = 24 KB
+struct LinkSlot {                                // one kept border; the fields change their meaning from phase to phase:
+    int a;                                       //   shoelace sum                    -> contour index (kNone: none emitted)
+    int b;                                       //   smallest outer-type key         -> canonical key | hole << 31 (-1: none)
+    int c;                                       //   smallest hole-type key          -> first write ticket
+    unsigned d;                                  //   border length n (low 16 bits)   -> | position of the canonical start << 16
 };
 __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsigned* __restrict__ n_starts, Counters* ctr,
                                                        const NodeRec* __restrict__ nodes, unsigned lds_nodes, unsigned* __restrict__ link_todo,
@@ -570,17 +572,19 @@ __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsi
         if (tid == 0) link_todo[f] = 1u;
         return;
     }
-    unsigned* sLink = reinterpret_cast<unsigned*>(dyn_lds);                     // next | steps << 16 (0xFFFF: none / saturated)
-    unsigned* sPair = sLink + lds_nodes;                                        // election: leader + 1 | pointer << 16; ranking: distance | pointer << 16
+    // 4 B + 1 bit of LDS per node (next and steps are read from the node records again where a phase starts from them).  A word whose
+    // top bit is set belongs to a leader (after phase 3: n | (0x8000 | slot) << 16, slot 0x7FFF = none) or to a poisoned node (0xFFFF0000);
+    // node indices stay below 0x8000.
+    unsigned* sPair = reinterpret_cast<unsigned*>(dyn_lds);                     // election: leader + 1 | pointer << 16; ranking: distance | pointer << 16
     LinkSlot* sSlot = reinterpret_cast<LinkSlot*>(sPair + lds_nodes);
-    unsigned short* sLead = reinterpret_cast<unsigned short*>(sSlot + kLinkSlots);   // leader + 1 (0: poisoned); of a leader: 0x8000 | slot, 0 without one
+    unsigned* sIsLeader = reinterpret_cast<unsigned*>(sSlot + kLinkSlots);      // one bit per node
     if (tid == 0) { sNSlots = 0; sActive = 0; }
+    for (unsigned i = tid; i < (nn + 31u) / 32u; i += kLinkThreads) sIsLeader[i] = 0u;
 
     // ---- 1. election ----
     for (unsigned i = tid; i < nn; i += kLinkThreads) {
         const NodeRec r = gn[i];
         const bool dead = r.state == kNone || r.nxt == kNone || r.nxt >= nn;
-        sLink[i] = (dead ? 0xFFFFu : r.nxt) | (min(r.len, 0xFFFFu) << 16);
         sPair[i] = dead ? (0u | (i << 16)) : ((i + 1u) | (r.nxt << 16));
     }
     __syncthreads();
@@ -596,18 +600,20 @@ __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsi
     // ---- 2. ranking ----
     for (unsigned i = tid; i < nn; i += kLinkThreads) {
         const unsigned lead = sPair[i] & 0xFFFFu;
-        sLead[i] = (unsigned short)lead;
+        unsigned w = 0xFFFF0000u;                              // poisoned
+        if (lead != 0u) {
+            const NodeRec r = gn[i];
+            w = min(r.len, 0xFFFFu) | (r.nxt << 16);           // (steps, next): a live node's next is valid
+            if (lead == i + 1u) atomicOr(&sIsLeader[i >> 5], 1u << (i & 31u));
+        }
+        sPair[i] = w;                                          // (every lane reads its own word only in this loop)
     }
-    __syncthreads();
-    for (unsigned i = tid; i < nn; i += kLinkThreads) sPair[i] = sLead[i] ? ((sLink[i] >> 16) | (sLink[i] << 16)) : 0u;     // (steps, next)
     __syncthreads();
     for (int r = 0; r <= rounds + 1; r++) {
         bool active = false;
         for (unsigned i = tid; i < nn; i += kLinkThreads) {
-            const unsigned lead = sLead[i];
-            if (lead == 0) continue;
             const unsigned w = sPair[i], p = w >> 16;
-            if (p == lead - 1u) continue;                      // the pointer stands on the leader
+            if (p >= 0x8000u || ((sIsLeader[p >> 5] >> (p & 31u)) & 1u)) continue;     // poisoned, or the pointer stands on the leader
             const unsigned wp = sPair[p];
             sPair[i] = min((w & 0xFFFFu) + (wp & 0xFFFFu), 0xFFFFu) | (wp & 0xFFFF0000u);
             active = true;
@@ -620,17 +626,17 @@ __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsi
     }
     // ---- 3. slots and sums ----
     for (unsigned i = tid; i < nn; i += kLinkThreads) {
-        if (sLead[i] != i + 1u) continue;                      // leaders only
-        const unsigned n = sPair[i] & 0xFFFFu;                 // all the way round
-        unsigned v = 0;
-        if ((int)n >= cfg.min_perim && (int)n <= cfg.max_perim && (sPair[i] >> 16) == i) {
+        if (!((sIsLeader[i >> 5] >> (i & 31u)) & 1u)) continue;                        // leaders only
+        const unsigned w = sPair[i], n = w & 0xFFFFu;          // all the way round
+        unsigned v = 0x7FFFu;
+        if ((int)n >= cfg.min_perim && (int)n <= cfg.max_perim && (w >> 16) == i) {
             const unsigned slot = atomicAdd(&sNSlots, 1u);
             if (slot < kLinkSlots) {
-                sSlot[slot] = LinkSlot{0, INT_MAX, INT_MAX, n, kNone, 0u, 0u, 0u};
-                v = 0x8000u | slot;
+                sSlot[slot] = LinkSlot{0, INT_MAX, INT_MAX, n};
+                v = slot;
             }
         }
-        sLead[i] = (unsigned short)v;
+        sPair[i] = n | ((0x8000u | v) << 16);                  // (no other lane reads a leader's word in this loop)
     }
     __syncthreads();
     if (sNSlots > kLinkSlots) {                                // uniform; nothing has left the workgroup yet
@@ -639,34 +645,45 @@ __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsi
     }
     if (tid == 0) link_todo[f] = 0u;
     auto slot_of = [&](unsigned i) -> int {                    // the slot of node i's border, -1 without one
-        unsigned v = sLead[i];
-        if (v == 0) return -1;
-        if (v < 0x8000u) v = sLead[v - 1u];
-        return v >= 0x8000u ? (int)(v & 0x7FFFu) : -1;
+        unsigned w = sPair[i];
+        if (!(w >> 31)) w = sPair[w >> 16];                    // the leader's word (a pointer that never reached a leader cannot be: the rounds suffice)
+        const unsigned v = (w >> 16) & 0x7FFFu;
+        return (w >> 31) && v != 0x7FFFu ? (int)v : -1;
     };
     for (unsigned i = tid; i < nn; i += kLinkThreads) {
         const int sl = slot_of(i);
         if (sl < 0) continue;
         const NodeRec r = gn[i];
-        atomicAdd(&sSlot[sl].area, r.area);
+        atomicAdd(&sSlot[sl].a, r.area);
         const unsigned type = (r.state >> 29) & 3u;
-        if (type == kNodeOuter) atomicMin(&sSlot[sl].kmin_outer, node_key(r.state, cols));
-        if (type == kNodeHole) atomicMin(&sSlot[sl].kmin_hole, node_key(r.state, cols));
+        if (type == kNodeOuter) atomicMin(&sSlot[sl].b, node_key(r.state, cols));
+        if (type == kNodeHole) atomicMin(&sSlot[sl].c, node_key(r.state, cols));
+    }
+    __syncthreads();
+    // the leader turns (area, smallest outer key, smallest hole key) into the border's type and its canonical key
+    for (unsigned i = tid; i < nn; i += kLinkThreads) {
+        if (!((sIsLeader[i >> 5] >> (i & 31u)) & 1u)) continue;
+        const unsigned v = (sPair[i] >> 16) & 0x7FFFu;
+        if (v == 0x7FFFu) continue;
+        LinkSlot& s = sSlot[v];
+        const bool is_hole = s.a > 0;                          // outer borders run counter-clockwise on screen
+        const int ckey = is_hole ? s.c : s.b;
+        s.b = ckey == INT_MAX ? -1 : (int)((unsigned)ckey | (is_hole ? 0x80000000u : 0u));
+        s.a = (int)kNone;                                      // no contour (yet)
     }
     __syncthreads();
     // ---- 4. the canonical start emits the contour ----
     for (unsigned i = tid; i < nn; i += kLinkThreads) {
         const int sl = slot_of(i);
         if (sl < 0) continue;
+        const unsigned want = (unsigned)sSlot[sl].b;
+        if (want == 0xFFFFFFFFu) continue;                     // no start candidate of the border's own type
         const NodeRec r = gn[i];
         const unsigned type = (r.state >> 29) & 3u;
-        if (type != kNodeOuter && type != kNodeHole) continue;
-        const LinkSlot s = sSlot[sl];
-        const bool is_hole = s.area > 0;                       // outer borders run counter-clockwise on screen
-        if (type != (is_hole ? kNodeHole : kNodeOuter)) continue;
-        const int ckey = is_hole ? s.kmin_hole : s.kmin_outer;
-        if (node_key(r.state, cols) != ckey) continue;
-        const unsigned n = s.n, wcap = (n + 63u) / 64u;
+        const bool is_hole = (want >> 31) != 0;
+        const int ckey = (int)(want & 0x7FFFFFFFu);
+        if (type != (is_hole ? kNodeHole : kNodeOuter) || node_key(r.state, cols) != ckey) continue;
+        const unsigned n = sSlot[sl].d & 0xFFFFu, wcap = (n + 63u) / 64u;
         const unsigned ci = atomicAdd(&n_contours[f], 1u);
         const unsigned off = atomicAdd(&n_points[f], n);
         const unsigned wbase = atomicAdd(&n_write[f], wcap);
@@ -681,9 +698,9 @@ __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsi
             contours[(size_t)f * cfg.cap_contours + ci] = ContourRec{(unsigned)f, sc, (unsigned)ckey, n, off, (short)cx, (short)cy,
                                                                     (int)((r.state >> 24) & 7u), {0u, 0u}};
             const unsigned dist = sPair[i] & 0xFFFFu;          // to the leader; the leader's own is n
-            sSlot[sl].pos_canon = n - dist;
-            sSlot[sl].wbase = wbase;
-            sSlot[sl].ci = ci;
+            sSlot[sl].d = n | ((n - dist) << 16);              // (the other lanes of this phase read the low half only: it does not change)
+            sSlot[sl].c = (int)wbase;
+            sSlot[sl].a = (int)ci;
         }
     }
     __syncthreads();
@@ -692,14 +709,16 @@ __global__ __launch_bounds__(kLinkThreads) void k_link(DetectCfg cfg, const unsi
         const int sl = slot_of(i);
         if (sl < 0) continue;
         const LinkSlot s = sSlot[sl];
-        if (s.ci == kNone) continue;
-        const unsigned n = s.n, len = sLink[i] >> 16;
-        unsigned rel = (n - (sPair[i] & 0xFFFFu)) + n - s.pos_canon;          // position after the canonical start, mod n
+        const unsigned ci = (unsigned)s.a;
+        if (ci == kNone) continue;
+        const NodeRec r = gn[i];
+        const unsigned n = s.d & 0xFFFFu, pos_canon = s.d >> 16, len = r.len;
+        unsigned rel = (n - (sPair[i] & 0xFFFFu)) + n - pos_canon;            // position after the canonical start, mod n
         while (rel >= n) rel -= n;
-        const unsigned state = gn[i].state;
-        WriteRec* wl = wlist + (size_t)f * cfg.cap_write + s.wbase;
+        const unsigned state = r.state;
+        WriteRec* wl = wlist + (size_t)f * cfg.cap_write + (unsigned)s.c;
         for (unsigned b = (rel + 63u) / 64u; 64u * b < min(rel + len, n); b++)
-            wl[b] = WriteRec{state, s.ci, 64u * b, min(64u, n - 64u * b) | ((64u * b - rel) << 16)};
+            wl[b] = WriteRec{state, ci, 64u * b, min(64u, n - 64u * b) | ((64u * b - rel) << 16)};
     }
 }
 
@@ -1672,7 +1691,7 @@ void launch_link(hipStream_t st, const DetectCfg& cfg, int nframes, const unsign
     // ASLAM_LINK_LDS_NODES: nodes of a frame the LDS image holds (a test knob: 0 sends every frame through k_link_serial)
     const char* env = std::getenv("ASLAM_LINK_LDS_NODES");
     const unsigned lds_nodes = env ? std::min((unsigned)std::atoi(env), kLinkLdsNodes) : kLinkLdsNodes;
-    const size_t dyn = (size_t)kLinkLdsNodes * 10u + sizeof(LinkSlot) * kLinkSlots;
+    const size_t dyn = (size_t)kLinkLdsNodes * 4u + sizeof(LinkSlot) * kLinkSlots + (kLinkLdsNodes + 31u) / 32u * 4u;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_link), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);

@@ -227,6 +227,9 @@ int aslam_comm_destroy(aslam_ctx* ctx);
 /* ---- instrumentation ---------------------------------------------------------------------------------
  * Stage taps used by the parity tests (tests/): what each detector stage produced for a staged slot. */
 int aslam_debug_get_nbr(aslam_ctx* ctx, int slot, int scale, uint8_t* out /* rows*cols */);
+/* list sizes of one slot after its last detection pass: border nodes, kept contours, contour points, write tickets, quad candidates, and
+ * whether the frame's node cycles went through the serial fallback kernel (more nodes / borders than the LDS image holds) */
+int aslam_debug_get_frame_counts(aslam_ctx* ctx, int slot, unsigned out[6]);
 int aslam_debug_get_contours(aslam_ctx* ctx, int slot, int scale, int max_contours, long long max_points,
                              int* n_contours, int* sizes, int* keys, int* points_xy, long long* n_points);
 int aslam_debug_get_candidates(aslam_ctx* ctx, int slot, int stage /*0 quads (unordered), 2 final*/, int max,
