@@ -72,7 +72,9 @@ def test_contours_degenerate_images(link, monkeypatch):
         ctx.set_camera(synth.camera_matrix(rows, cols, 100.0), np.zeros(5))
         ctx.set_detector_params(maxMarkerPerimeterRate=40.0)       # keep the long borders: they are the point
         for trial in range(trials):
-            if trial % 5 == 3:
+            if trial % 5 == 2 and rows > 100:
+                img = rng.randint(0, 256, (rows, cols)).astype(np.uint8)   # pure noise: more kept borders than k_link has slots -> it hands the frame over
+            elif trial % 5 == 3:
                 img = _spiral(rows, cols, 4 + trial)
             elif trial % 5 == 4:
                 img = np.full((rows, cols), 210, np.uint8)
