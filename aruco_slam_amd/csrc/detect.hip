@@ -1275,15 +1275,31 @@ __global__ __launch_bounds__(1024) void k_assemble(DetectCfg cfg, Counters* ctr,
     __syncthreads();
     // _filterTooCloseCandidates, part 1: near pairs (i < j).  A cheap exact pre-test skips far pairs: the mean
     // squared corner distance of any cyclic matching is >= the squared distance between the corner centroids.
-    for (int p = tid; p < C * C; p += AT) {
-        int i = p / C, j = p - i * C;
-        if (j > i) {
-            const CandRec& a = sC[i];
+    // every unordered pair exactly once: candidate a against the next (C - 1) / 2 candidates in cyclic order (and, for even C, the
+    // first half against the one opposite); the quotient p / half by a float reciprocal, corrected to the exact value
+    const int half = (C - 1) / 2, extra = (C & 1) == 0 ? C / 2 : 0;
+    const float inv_half = half > 0 ? 1.0f / (float)half : 0.f;
+    for (int p = tid; p < C * half + extra; p += AT) {
+        int a, k;
+        if (p < C * half) {
+            a = (int)(((float)p + 0.5f) * inv_half);
+            if (a * half > p) a--;
+            if ((a + 1) * half <= p) a++;
+            k = p - a * half + 1;                                   // 1 .. half
+        } else {
+            a = p - C * half;                                       // 0 .. C / 2 - 1
+            k = C / 2;
+        }
+        int b2 = a + k;
+        if (b2 >= C) b2 -= C;
+        const int i = min(a, b2), j = max(a, b2);
+        {
+            const CandRec& ca = sC[i];
             const CandRec& bq = sC[j];
-            int minimumPerimeter = (int)min(a.n, bq.n);
+            int minimumPerimeter = (int)min(ca.n, bq.n);
             double minMarkerDistancePixels = (double)minimumPerimeter * cfg.min_marker_dist_rate;
             double thr = minMarkerDistancePixels * minMarkerDistancePixels;
-            int sax = a.x[0] + a.x[1] + a.x[2] + a.x[3], say = a.y[0] + a.y[1] + a.y[2] + a.y[3];
+            int sax = ca.x[0] + ca.x[1] + ca.x[2] + ca.x[3], say = ca.y[0] + ca.y[1] + ca.y[2] + ca.y[3];
             int sbx = bq.x[0] + bq.x[1] + bq.x[2] + bq.x[3], sby = bq.y[0] + bq.y[1] + bq.y[2] + bq.y[3];
             double cdx = (double)(sax - sbx) * 0.25, cdy = (double)(say - sby) * 0.25;
             bool near = false;
@@ -1292,7 +1308,7 @@ __global__ __launch_bounds__(1024) void k_assemble(DetectCfg cfg, Counters* ctr,
                     double distSq = 0;
                     for (int c = 0; c < 4; c++) {
                         int modC = (c + fc) & 3;
-                        double ddx = (double)(a.x[modC] - bq.x[c]), ddy = (double)(a.y[modC] - bq.y[c]);
+                        double ddx = (double)(ca.x[modC] - bq.x[c]), ddy = (double)(ca.y[modC] - bq.y[c]);
                         distSq += ddx * ddx + ddy * ddy;
                     }
                     distSq /= 4.;
@@ -1315,18 +1331,44 @@ __global__ __launch_bounds__(1024) void k_assemble(DetectCfg cfg, Counters* ctr,
         sPairSorted[rank] = k;
     }
     __syncthreads();
-    // part 2: sequential marking in pair order (depends on earlier removals)
+    // part 2: sequential marking in pair order (depends on earlier removals).  Which of the two a pair would remove does not depend
+    // on the marks: all threads work that out first, so that the one marking thread has a single LDS word to fetch per pair (its
+    // address does not depend on the marks either: the fetches run ahead of the marking)
+    for (int q = tid; q < P; q += AT) {
+        const unsigned k = sPairSorted[q];
+        const unsigned i = k >> 16, j = k & 0xFFFFu;
+        sPair[q] = k | (sC[i].n > sC[j].n ? 0x80000000u : 0u);      // top bit: the pair removes j (candidate indices are below 2^11)
+    }
+    __syncthreads();
     if (tid == 0) {
         for (int q = 0; q < P; q++) {
-            int i = (int)(sPairSorted[q] >> 16), j = (int)(sPairSorted[q] & 0xFFFFu);
+            const unsigned k = sPair[q];
+            const int i = (int)((k >> 16) & 0x7FFFu), j = (int)(k & 0xFFFFu);
             if (removed[i] || removed[j]) continue;
-            if (sC[i].n > sC[j].n) removed[j] = 1;
-            else removed[i] = 1;
+            removed[(k >> 31) ? j : i] = 1;
         }
-        int k = 0;
-        for (int i = 0; i < C; i++) { outPos[i] = removed[i] ? -1 : k; k += removed[i] ? 0 : 1; }
-        n_final[f] = (unsigned)k;
-        sWorkBase = k > 0 ? atomicAdd(&ctr->n_ident, (unsigned)k) : 0u;
+    }
+    __syncthreads();
+    // positions of the survivors: an ordered compaction by all threads (ballot ranks, wave offsets through LDS)
+    {
+        __shared__ int sWaveCnt[AT / 64];
+        int kbase = 0;
+        for (int i0 = 0; i0 < C; i0 += AT) {                        // uniform
+            const int i = i0 + tid;
+            const bool keep = i < C && !removed[i];
+            const unsigned long long m = __ballot(keep);
+            if ((tid & 63) == 0) sWaveCnt[tid >> 6] = __popcll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < AT / 64; w++) { const int c = sWaveCnt[w]; if (w < (tid >> 6)) before += c; total += c; }
+            if (i < C) outPos[i] = keep ? kbase + before + __popcll(m & ((1ull << (tid & 63)) - 1ull)) : -1;
+            kbase += total;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            n_final[f] = (unsigned)kbase;
+            sWorkBase = kbase > 0 ? atomicAdd(&ctr->n_ident, (unsigned)kbase) : 0u;
+        }
     }
     __syncthreads();
     for (int i = tid; i < C; i += AT) {
