@@ -361,7 +361,7 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
         prof_end(c);
         prof_begin(c, P_WRITE, st);
         launch_prefix(st, nf, c->d_nwrite + f0, g.cap_write, 1u, c->d_pre_write);
-        launch_trace_write(st, std::max(64, c->nwaves / 4), nbr, g, nf, c->d_pre_write, c->d_ctr, contours, wlist, points);
+        launch_trace_write(st, std::max(64, c->nwaves / 4), nbr, g, nf, c->d_pre_write, c->d_ctr, contours, wlist, c->d_nwrite + f0, points);
         prof_end(c);
         prof_begin(c, P_QUADS, st);
         launch_prefix(st, nf, c->d_ncontours + f0, g.cap_contours, 1u, c->d_pre_quads);
@@ -665,10 +665,20 @@ int aslam_stage_frames(aslam_ctx* c, int slot0, const uint8_t* frames, int nfram
     r = quiesce_slots(c, slot0, nframes);
     if (r) return r;
     c->in_frame_bytes = (size_t)rows * cols * channels;
-    for (int f = 0; f < nframes; f++)
-        HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)(slot0 + f) * c->in_frame_bytes, (size_t)cols * channels,
-                                    frames + (size_t)f * frame_stride, step, (size_t)cols * channels, rows,
-                                    hipMemcpyHostToDevice, c->stream));
+    const bool tight = step == (size_t)cols * channels;        // (a plain copy for tight rows: the 2-D path goes row by row for pageable memory)
+    if (tight && (nframes == 1 || frame_stride == c->in_frame_bytes)) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_in + (size_t)slot0 * c->in_frame_bytes, frames, c->in_frame_bytes * nframes, hipMemcpyHostToDevice, c->stream));
+    } else {
+        for (int f = 0; f < nframes; f++) {
+            if (tight)
+                HIP_TRY(c, hipMemcpyAsync(c->d_in + (size_t)(slot0 + f) * c->in_frame_bytes, frames + (size_t)f * frame_stride, c->in_frame_bytes,
+                                          hipMemcpyHostToDevice, c->stream));
+            else
+                HIP_TRY(c, hipMemcpy2DAsync(c->d_in + (size_t)(slot0 + f) * c->in_frame_bytes, (size_t)cols * channels,
+                                            frames + (size_t)f * frame_stride, step, (size_t)cols * channels, rows,
+                                            hipMemcpyHostToDevice, c->stream));
+        }
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));      // px is borrowed for the call only
     return ASLAM_OK;
 }

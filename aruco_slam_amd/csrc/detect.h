@@ -15,7 +15,7 @@ void launch_seg(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg&
 void launch_link(hipStream_t st, const DetectCfg& cfg, int nframes, const unsigned* n_starts, Counters* ctr, const NodeRec* nodes,
                  unsigned* link_todo, ContourRec* contours, unsigned* n_contours, unsigned* n_points, WriteRec* wlist, unsigned* n_write);
 void launch_trace_write(hipStream_t st, int nblocks, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* pre,
-                        Counters* ctr, const ContourRec* contours, const WriteRec* wlist, unsigned* points);
+                        Counters* ctr, const ContourRec* contours, const WriteRec* wlist, const unsigned* n_write, unsigned* points);
 void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, int nframes, Counters* ctr, const ContourRec* contours,
                   const unsigned* n_contours, const unsigned* pre, const unsigned* points, CandRec* cands, unsigned* n_cand);
 void launch_assemble(hipStream_t st, int nframes, const DetectCfg& cfg, Counters* ctr, const CandRec* cands,

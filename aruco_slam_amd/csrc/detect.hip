@@ -390,6 +390,17 @@ __device__ __forceinline__ int ticket_frame(const unsigned* sPre, int nframes, u
 
 constexpr int kMaxFramesPerCall = 1024;
 
+// The ticket ranges of a work-queue kernel into LDS: the prefix k_prefix made - or, for a call of one frame, straight from the
+// frame's count (the host then skips the k_prefix launch: the single-frame call is a chain of small launches)
+__device__ __forceinline__ void load_ticket_ranges(unsigned* sPre, const unsigned* __restrict__ pre, const unsigned* __restrict__ counts,
+                                                   unsigned cap, int nframes, int tid, int nthreads) {
+    if (nframes == 1) {
+        if (tid == 0) { sPre[0] = 0u; sPre[1] = min(counts[0], cap); }
+    } else {
+        for (int i = tid; i <= nframes; i += nthreads) sPre[i] = pre[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_seg / k_link / k_trace_write : Suzuki-Abe border following without the sequential raster scan, in segments
 // ------------------------------------------------------------------------------------------------
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(64) void k_seg(const uint8_t* __restrict__ nbr, Det
     __shared__ unsigned short sStep[256 * 8];
     const int lane = threadIdx.x & 63;
     build_step_table(sStep, lane, 64);
-    for (int i = lane; i <= nframes; i += 64) sPre[i] = pre[i];
+    load_ticket_ranges(sPre, pre, n_starts, cfg.cap_starts, nframes, lane, 64);
     __syncthreads();
     const unsigned total = sPre[nframes];
     const int pitch = cfg.pitch;
@@ -856,14 +867,14 @@ __global__ __launch_bounds__(512) void k_link_serial(DetectCfg cfg, const unsign
 __global__ __launch_bounds__(256) void k_trace_write(const uint8_t* __restrict__ nbr, DetectCfg cfg, int nframes,
                                                      const unsigned* __restrict__ pre, Counters* ctr,
                                                      const ContourRec* __restrict__ contours, const WriteRec* __restrict__ wlist,
-                                                     unsigned* __restrict__ points) {
+                                                     const unsigned* __restrict__ n_write, unsigned* __restrict__ points) {
     __shared__ unsigned sPre[kMaxFramesPerCall + 1];
     __shared__ unsigned sPts[4][64][64];
     __shared__ unsigned short sStep[256 * 8];
     __shared__ unsigned sBase;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     build_step_table(sStep, tid, 256);
-    for (int i = tid; i <= nframes; i += 256) sPre[i] = pre[i];
+    load_ticket_ranges(sPre, pre, n_write, cfg.cap_write, nframes, tid, 256);
     __syncthreads();
     const unsigned total = sPre[nframes];
     const int pitch = cfg.pitch;
@@ -1151,7 +1162,7 @@ __global__ __launch_bounds__(64) void k_quads(DetectCfg cfg, int nframes, Counte
                                               unsigned* __restrict__ n_cand) {
     __shared__ unsigned sPre[kMaxFramesPerCall + 1];
     const int lane = threadIdx.x & 63;
-    for (int i = lane; i <= nframes; i += 64) sPre[i] = pre[i];
+    load_ticket_ranges(sPre, pre, n_contours, cfg.cap_contours, nframes, lane, 64);
     __syncthreads();
     const unsigned total = sPre[nframes];
 #ifdef ASLAM_QUADS_STAMPS
@@ -1722,6 +1733,7 @@ void launch_clear_counts(hipStream_t st, int nframes, Counters* ctr, unsigned* n
                        n_write, n_cand);
 }
 void launch_prefix(hipStream_t st, int nframes, const unsigned* counts, unsigned cap, unsigned per_ticket, unsigned* pre) {
+    if (nframes == 1 && per_ticket == 1u) return;              // the consumers take a single frame's range from its count (load_ticket_ranges)
     hipLaunchKernelGGL(k_prefix, dim3(1), dim3(256), 0, st, nframes, counts, cap, per_ticket, pre);
 }
 void launch_seg(hipStream_t st, int nwaves, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* starts,
@@ -1744,8 +1756,8 @@ void launch_link(hipStream_t st, const DetectCfg& cfg, int nframes, const unsign
     hipLaunchKernelGGL(k_link_serial, dim3(nframes), dim3(512), 0, st, cfg, n_starts, ctr, nodes, link_todo, contours, n_contours, n_points, wlist, n_write);
 }
 void launch_trace_write(hipStream_t st, int nblocks, const uint8_t* nbr, const DetectCfg& cfg, int nframes, const unsigned* pre,
-                        Counters* ctr, const ContourRec* contours, const WriteRec* wlist, unsigned* points) {
-    hipLaunchKernelGGL(k_trace_write, dim3(nblocks), dim3(256), 0, st, nbr, cfg, nframes, pre, ctr, contours, wlist, points);
+                        Counters* ctr, const ContourRec* contours, const WriteRec* wlist, const unsigned* n_write, unsigned* points) {
+    hipLaunchKernelGGL(k_trace_write, dim3(nblocks), dim3(256), 0, st, nbr, cfg, nframes, pre, ctr, contours, wlist, n_write, points);
 }
 void launch_quads(hipStream_t st, int nwaves, const DetectCfg& cfg, int nframes, Counters* ctr, const ContourRec* contours,
                   const unsigned* n_contours, const unsigned* pre, const unsigned* points, CandRec* cands, unsigned* n_cand) {
