@@ -319,7 +319,10 @@ int run_detect(aslam_ctx* c, int first, int count, bool beside_ekf = false, hipE
     if (c->last_detect && c->last_detect != st) HIP_TRY(c, hipStreamWaitEvent(st, c->ev_detect, 0));   // slots / work lists are shared
     c->last_detect = st;
     if (wait_before) HIP_TRY(c, hipStreamWaitEvent(st, wait_before, 0));          // frames still in flight on the copy stream
-    const DetectCfg& g = c->cfg;
+    DetectCfg g = c->cfg;
+    // one frame (the drop-in call): a finer cut lattice - its longest segment sets the latency of k_seg / k_trace_write, and the extra nodes
+    // (x 1.6) still fit k_link's LDS image for frames up to a megapixel or so
+    g.cut_mask = (count == 1 && (size_t)g.rows * g.cols <= (size_t)1200 * 1000 ? kCutGridSingle : kCutGrid) - 1;
     const size_t frame_px = (size_t)g.rows * g.cols;
     const bool alias_gray = c->channels == 1;              // staged gray frames are tight: the detector reads them in place
     c->last_first = first;

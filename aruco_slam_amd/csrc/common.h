@@ -50,6 +50,7 @@ struct DetectCfg {
     int max_corr;                     // int(maxCorrectionBits * errorCorrectionRate)
     int n_dict;                       // markers in the dictionary
     double min_otsu_std;              // 5.0
+    int cut_mask;                     // pitch of the cut lattice - 1 (set per call)
     unsigned cap_starts, cap_contours, cap_points, cap_write;   // per frame (cap_starts: border nodes = start candidates + cut states; cap_write: write tickets)
 };
 
@@ -69,12 +70,13 @@ struct ContourRec {
 // nodes of a frame are the states that cut those cycles into short segments, all decidable from the 3x3 neighbourhood:
 //   * the start candidates of the sequential raster scan (outer type: foreground with W / NW / N / NE background; hole type:
 //     foreground with E background and NE foreground, i.e. the pixel left of a background pixel whose W and N are foreground),
-//   * cut states: any state on a pixel of the kCutGrid lattice (x or y a multiple of kCutGrid) whose first examined neighbour
+//   * cut states: any state on a pixel of the cut lattice (x or y a multiple of its pitch, DetectCfg::cut_mask + 1) whose first examined neighbour
 //     (direction s + 1) is background - such a state hugs a background pixel, so its cycle is a real border.
 // k_threshold lists them (packed as below), k_seg walks each node's segment to the next node, k_link follows the node cycles
 // (dozens of hops instead of thousands of pixel steps) to elect the canonical start and to cut the kept borders into write
 // tickets, and k_trace_write replays those in parallel.
-constexpr int kCutGrid = 64;      // power of two, divides the 64-pixel tile width of k_threshold
+constexpr int kCutGrid = 64;      // pitch of the cut lattice of a batch: a power of two that divides the 64-pixel tile width of k_threshold and is a multiple of 4
+constexpr int kCutGridSingle = 32; // ... of a call of one frame: the longest segment sets its latency, and the node count does not matter there
 constexpr unsigned kNodeCut = 0u, kNodeOuter = 1u, kNodeHole = 2u, kNodeInvalid = 3u;   // type field
 constexpr unsigned kNone = 0xFFFFFFFFu;
 // x[0:12) y[12:24) s[24:27) scale[27:29) type[29:31)

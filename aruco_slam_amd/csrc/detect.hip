@@ -254,10 +254,10 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
     for (int u = tid; u < TH * TW / 4; u += 256) {
         const int ty = u / (TW / 4), tx4 = (u - ty * (TW / 4)) * 4;
         const int gy = y0 + ty;
-        const bool row_on_grid = (gy & (kCutGrid - 1)) == 0;
-        // which of the thread's four pixels lie on the cut lattice (x0 is a multiple of kCutGrid); pixels beyond the frame are never foreground
-        const unsigned grid4 = row_on_grid ? 15u : ((tx4 & (kCutGrid - 1)) == 0 ? 1u : 0u);
-        static_assert(kCutGrid % 4 == 0, "a thread's four pixels start on a multiple of 4");
+        const bool row_on_grid = (gy & cfg.cut_mask) == 0;
+        // which of the thread's four pixels lie on the cut lattice (its pitch divides the tile width and is a multiple of 4: x0 + tx4 is on it
+        // iff tx4 is); pixels beyond the frame are never foreground
+        const unsigned grid4 = row_on_grid ? 15u : ((tx4 & cfg.cut_mask) == 0 ? 1u : 0u);
         unsigned out[kScales] = {0, 0, 0};
         unsigned emit = 0;                                          // bit 4 s + j: pixel j of scale s may carry nodes
 #pragma unroll
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
             const bool outer = m != 0 && (m & 0x1Eu) == 0, hole = (m & 3u) == 2u;
             const unsigned s0 = outer ? (unsigned)first_outer(m) : (unsigned)first_hole(m);
             unsigned cut = 0;
-            if (row_on_grid || (gx & (kCutGrid - 1)) == 0) cut = m & ~((m >> 1) | (m << 7)) & 0xFFu;   // neighbour s foreground, neighbour s + 1 background
+            if (row_on_grid || (gx & (unsigned)cfg.cut_mask) == 0) cut = m & ~((m >> 1) | (m << 7)) & 0xFFu;   // neighbour s foreground, neighbour s + 1 background
             if (outer || hole) cut &= ~(1u << s0);                  // the candidate's own state is listed once
             const unsigned cnt = (unsigned)__popc(cut) + ((outer || hole) ? 1u : 0u);
             if (cnt == 0) continue;
@@ -426,7 +426,7 @@ constexpr int kTraceChunk = 64;      // tickets per grab: one per lane
 
 // One border-following step as a table: (neighbour mask m, back direction s) -> dx + 1 | dy + 1 << 2 | new s << 4 | "this state is an
 // outer-type start candidate" << 7 | "... a hole-type one" << 8 | "the first examined neighbour s + 1 is background: a cut state where
-// the pixel lies on the kCutGrid lattice" << 9.  A walk is one dependent chain, so the ~35 instructions of walk_step become one LDS read.
+// the pixel lies on the cut lattice" << 9.  A walk is one dependent chain, so the ~35 instructions of walk_step become one LDS read.
 __device__ __forceinline__ void build_step_table(unsigned short* sStep, int tid, int nthreads) {
     for (int i = tid; i < 256 * 8; i += nthreads) {
         const unsigned m = (unsigned)i >> 3;
@@ -440,7 +440,7 @@ __device__ __forceinline__ void build_step_table(unsigned short* sStep, int tid,
                                     (cut ? 0x200u : 0u));
     }
 }
-__device__ __forceinline__ bool on_cut_grid(int x, int y) { return ((x & (kCutGrid - 1)) == 0) || ((y & (kCutGrid - 1)) == 0); }
+__device__ __forceinline__ bool on_cut_grid(int x, int y, int mask) { return ((x & mask) == 0) || ((y & mask) == 0); }
 
 // k_seg: work-queue kernel, one lane per node (ticket = node of the whole call; `pre` = per-frame prefix of the node counts).
 // Every lane is a small state machine (idle -> walk -> idle); idle lanes are refilled from the queue with one atomic per 64
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(64) void k_seg(const uint8_t* __restrict__ nbr, Det
             if (mode == 1) {
                 const unsigned m = plane[nbr_index(w.x, w.y, pitch)];
                 const unsigned st = sStep[(m << 3) | (unsigned)w.s];
-                const bool arrived = n > 0 && ((st & 0x180u) != 0 || ((st & 0x200u) != 0 && on_cut_grid(w.x, w.y)));
+                const bool arrived = n > 0 && ((st & 0x180u) != 0 || ((st & 0x200u) != 0 && on_cut_grid(w.x, w.y, cfg.cut_mask)));
                 if (arrived) {
                     // the node standing on this state: the nodes of a pixel are consecutive in the frame's list
                     const unsigned want = pack_node((unsigned)w.x, (unsigned)w.y, (unsigned)w.s, (state0 >> 27) & 3u, 0u);
