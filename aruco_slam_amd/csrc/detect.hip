@@ -955,6 +955,18 @@ __device__ __forceinline__ void wave_first_max(double& d, int& pos) {
         if (od > d || (od == d && op < pos)) { d = od; pos = op; }
     }
 }
+// The same for distances that are non-negative integers below 2^32 held exactly in doubles (approxPolyDP: squared distances and
+// cross products of pixel coordinates, < 2^26) and positions >= 0: one 64-bit key (distance, ~position) per lane, two thirds of the
+// lane-to-lane traffic of the general form.
+__device__ __forceinline__ void wave_first_max_exact(double& d, int& pos) {
+    unsigned long long key = ((unsigned long long)(unsigned)d << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)pos);
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ok = __shfl_xor(key, o);
+        key = ok > key ? ok : key;
+    }
+    d = (double)(unsigned)(key >> 32);
+    pos = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+}
 
 // Returns the number of vertices (<= 8) written to out, or -1 when the result cannot have 4 vertices.
 // Early exit rule: every stack slice yields at least one vertex and the final clean-up removes at most
@@ -1012,7 +1024,7 @@ __device__ int approx_poly_closed_body(const unsigned* __restrict__ gsrc, const 
             }
         }
         QST(0);
-        wave_first_max(best, bestj);
+        wave_first_max_exact(best, bestj);
         QST(1);
         if (best > 0.0) right_slice.start = bestj;          // unchanged when no point is farther than 0 (as in the scan)
         le_eps = best <= eps;
@@ -1059,7 +1071,7 @@ __device__ int approx_poly_closed_body(const unsigned* __restrict__ gsrc, const 
                 }
             }
             QST(3);
-            wave_first_max(best, bestt);
+            wave_first_max_exact(best, bestt);
             QST(1);
             if (best > 0.0) { int idx = first + bestt; if (idx >= count) idx -= count; right_slice.start = idx; }
             le_eps = best * best <= eps * (dx * dx + dy * dy);
