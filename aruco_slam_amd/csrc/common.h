@@ -13,6 +13,13 @@
 #define ASLAM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// Wait of one wave for a value another wave of the SAME workgroup writes to LDS (both resident by construction, the writer never waits
+// for the reader): polls with s_sleep, gives up after a bounded number of polls rather than hang the device.  (The CPU emulation runs
+// the lanes of a workgroup as coroutines and yields instead.)
+#ifndef ASLAM_SPIN_UNTIL
+#define ASLAM_SPIN_UNTIL(cond) do { for (int spin_ = 0; !(cond) && spin_ < (1 << 22); spin_++) __builtin_amdgcn_s_sleep(1); } while (0)
+#endif
+
 // The dynamic LDS allocation of a launch (the CPU emulation gives every workgroup a fixed array).
 #ifndef ASLAM_DYN_LDS
 #define ASLAM_DYN_LDS(name) extern __shared__ __align__(16) unsigned char name[]

@@ -152,11 +152,13 @@ __device__ void win_chain_role(const EkfState& E, const SlamParams& sp, const Wi
     for (int e = tid; e < SP; e += NT) sS[e] = e < s ? win_state_index(wd, e) : 0;
     for (int e = tid; e < 2 * 4 * SPP; e += NT) { (&sA[0][0][0])[e] = 0.0; (&sB[0][0][0])[e] = 0.0; }
     for (int e = tid; e < 2 * 6 * SPP; e += NT) (&sPub[0][0][0])[e] = 0.0;
-    if (tid == 0) {
-        int o = 0;
-        for (int k = 0; k < wd.K; k++) { sOff[k] = o; o += 1 + frames[wd.first_slot + k].m; }
-        sOff[wd.K] = o;
-    }
+    // steps per frame (1 predict + m corrections), every frame's count loaded by its own thread (one thread walking the plan would
+    // pay one dependent global load per frame), then the running sum
+    if (tid < wd.K) sOff[tid + 1] = 1 + frames[wd.first_slot + tid].m;
+    if (tid == 0) sOff[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int k = 0; k < wd.K; k++) sOff[k + 1] += sOff[k];
     __syncthreads();
     const int NS = sOff[wd.K];                                    // steps of the piece: per frame one predict + m corrections
     for (int k = 0; k < wd.K; k++) {

@@ -339,6 +339,7 @@ template <class F> void run_grid(const char*, dim3 grid, dim3 block, F&& body) {
 #define ASLAM_DYN_LDS(name) alignas(16) static thread_local unsigned char name[160 * 1024]
 #define ASLAM_RCP_ESTIMATE(x) (1.0 / (x))
 #define ASLAM_WAVE_BCAST(v, src) __shfl(v, src)
+#define ASLAM_SPIN_UNTIL(cond) do { while (!(cond)) hipemu::yield_lane(); } while (0)
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::run_grid(#kernel, dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); })
