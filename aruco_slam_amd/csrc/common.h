@@ -154,10 +154,5 @@ __host__ __device__ inline size_t nbr_index(int x, int y, int pitch) {
 }
 __host__ __device__ inline size_t nbr_plane_bytes(int rows, int pitch) { return (size_t)((rows + 7) & ~7) * (size_t)pitch; }
 
-// start-list entry: x[0:12) y[12:24) scale[24:26) type[26] frame[32:48)
-__host__ __device__ inline unsigned long long pack_start(unsigned x, unsigned y, unsigned scale, unsigned type, unsigned frame) {
-    return (unsigned long long)x | ((unsigned long long)y << 12) | ((unsigned long long)scale << 24) |
-           ((unsigned long long)type << 26) | ((unsigned long long)frame << 32);
-}
 
 } // namespace aslam

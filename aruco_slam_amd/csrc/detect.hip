@@ -941,10 +941,6 @@ __global__ __launch_bounds__(256) void k_trace_write(const uint8_t* __restrict__
 struct IPt { int x, y; };
 constexpr int kQuadLdsPts = 1536;     // 6 KB per wavefront (with the rest: 15 wavefronts per CU)
 constexpr int kQuadGrab = 4;          // contours per grab of k_quads
-__device__ __forceinline__ IPt ld_pt(const unsigned* p, int i) {
-    unsigned v = p[i];
-    return IPt{(int)(short)(v & 0xFFFFu), (int)(short)(v >> 16)};
-}
 
 // wave-wide "first maximum": the sequential scans use a strict '>' so the earliest position attaining the maximum wins;
 // distances here are integers held exactly in doubles, so the parallel reduction is bit-identical to the scan.
