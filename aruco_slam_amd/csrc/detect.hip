@@ -418,6 +418,7 @@ __device__ __forceinline__ void walk_step(Walk& w, unsigned m) {
 }
 
 constexpr int kTraceChunk = 64;      // tickets per grab: one per lane
+constexpr int kSegRepsBusy = 32, kSegRepsRefill = 8;   // steps per round of k_seg when nothing can be picked up / when idle lanes wait for a refill (measured: 8 / 2 0.672 ms, 16 / 4 0.648, 32 / 8 0.627 per 320 frames)
 
 // A border's canonical start - the state the sequential raster scan starts it from - is the start candidate of the border's own
 // type (outer / hole) with the smallest raster key on the cycle: the scan meets the border's topmost-leftmost pixel (outer) or the
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(64) void k_seg(const uint8_t* __restrict__ nbr, Det
             continue;
         }
         // several steps per round when nothing can be picked up anyway
-        const int reps = (idle == 0ull || drained) ? 16 : 4;      // wave-uniform
+        const int reps = (idle == 0ull || drained) ? kSegRepsBusy : kSegRepsRefill;      // wave-uniform
         for (int rep = 0; rep < reps; rep++) {
             if (mode == 1) {
                 const unsigned m = plane[nbr_index(w.x, w.y, pitch)];
