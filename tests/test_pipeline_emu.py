@@ -26,6 +26,11 @@ def test_detector_stages_small_scene():
     ctx.sync()
     got_ids, corners, rv, tv = pc.check_stages(ctx, 0, img, expect_ids=ids)
     pc.check_poses(got_ids, corners, rv, tv, K, D)
+    # list sizes of the pass (aslam_debug_get_frame_counts): every kept contour has its write tickets, 64 points each
+    fc = ctx.debug_frame_counts(0)
+    n_contours = sum(len(ctx.debug_contours(0, s)[0]) for s in range(3))
+    assert fc["contours"] == n_contours and fc["nodes"] >= fc["contours"] and fc["serial_link"] == 0
+    assert fc["points"] <= 64 * fc["write_tickets"] < fc["points"] + 64 * fc["contours"]
 
 
 def test_detector_bgr_and_odd_size():
