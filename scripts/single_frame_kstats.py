@@ -6,7 +6,7 @@ import numpy as np
 from aruco_slam_amd import capi, synth
 cfg = synth.CONFIGS["cfg2"]; w = synth.make_world(cfg); n = 40
 ctx = capi.Context(max_rows=cfg.rows, max_cols=cfg.cols, max_batch=1, max_landmarks=w.L + 8)
-ctx.set_camera(w.K, np.zeros(5)); synth.apply_detector(cfg, ctx)
+ctx.set_camera(w.K, np.zeros(5))      # default DetectorParameters, as the reference node runs
 frs = [w.frame(i) for i in range(n)]
 imgs = [ctx.synth_render(0, cfg.rows, cfg.cols, w.K, f.ids, f.poses, noise_amp=2, seed=i) for i, f in enumerate(frs)]
 bgr = [np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2)) for g in imgs]
