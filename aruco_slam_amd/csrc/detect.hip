@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
                                                    uint8_t* __restrict__ nbr, DetectCfg cfg,
                                                    unsigned* __restrict__ starts, unsigned* __restrict__ n_starts,
                                                    unsigned* __restrict__ nodeplane, Counters* ctr, int nframes) {
-    __shared__ uint8_t g[LH][LW];
+    __shared__ uint8_t g[LH][LW + 4];                          // (row pitch 23 words, odd: the row sums below read it with lane = row)
     __shared__ unsigned I[LH + 1][LW + 1];
     __shared__ unsigned long long sRow[kScales][TH + 2];     // threshold decisions of ring row by, columns x0 - 1 .. x0 + 62 (bit = column)
     __shared__ unsigned long long sRing[kScales][2];         // ... of columns x0 + 63 and x0 + 64 (bit = ring row)
@@ -156,34 +156,34 @@ __global__ __launch_bounds__(256) void k_threshold(const uint8_t* __restrict__ i
         }
     }
 
-    // 2. integral image I[y+1][x+1] = sum_{y'<=y, x'<=x} g : rows by 4 threads each (22 px), then columns by 2 threads each
-    if (tid < LH * 4) {
-        const int r = tid >> 2, q = tid & 3;
-        unsigned s = 0;
-        for (int k = 0; k < LW / 4; k++) { s += g[r][q * (LW / 4) + k]; I[r + 1][q * (LW / 4) + k + 1] = s; }
-    }
-    if (tid < LW + 1) I[0][tid] = 0;
-    if (tid < LH) I[tid + 1][0] = 0;
-    __syncthreads();
+    // 2. integral image I[y+1][x+1] = sum_{y'<=y, x'<=x} g.  Row sums: wave q takes the q-th quarter of the columns (22), lane = row, so
+    //    that the 64 lanes of an access stand in 64 different rows: the row pitch of I (89 words, odd) spreads them over all LDS banks
+    //    (with a wave spanning 16 rows x 4 quarters, half of the kernel's LDS cycles were bank conflicts).  Column sums: lane = column.
     {
-        const int r = tid >> 2, q = tid & 3;
+        const int q = tid >> 6, r = tid & 63;
+        if (r < LH) {
+            unsigned s = 0;
+            for (int k = 0; k < LW / 4; k++) { s += g[r][q * (LW / 4) + k]; I[r + 1][q * (LW / 4) + k + 1] = s; }
+        }
+        if (tid < LW + 1) I[0][tid] = 0;
+        if (tid < LH) I[tid + 1][0] = 0;
+        __syncthreads();
         unsigned add = 0;
-        if (tid < LH * 4)
+        if (r < LH)
             for (int qq = 0; qq < q; qq++) add += I[r + 1][(qq + 1) * (LW / 4)];     // totals of the preceding quarters (still local sums)
         __syncthreads();
-        if (tid < LH * 4 && q > 0)
+        if (r < LH && q > 0)
             for (int k = 0; k < LW / 4; k++) I[r + 1][q * (LW / 4) + k + 1] += add;
     }
     __syncthreads();
-    if (tid < LW * 2) {
-        const int c = tid >> 1, h = tid & 1;
-        unsigned s = 0;
-        for (int k = 0; k < LH / 2; k++) { s += I[h * (LH / 2) + k + 1][c + 1]; I[h * (LH / 2) + k + 1][c + 1] = s; }
-    }
-    __syncthreads();
-    if (tid < LW * 2) {
-        const int c = tid >> 1, h = tid & 1;
-        if (h == 1) {
+    {
+        const int h = tid >> 7, c = tid & 127;                     // two waves per half of the rows: columns 0..63 and 64..87
+        if (c < LW) {
+            unsigned s = 0;
+            for (int k = 0; k < LH / 2; k++) { s += I[h * (LH / 2) + k + 1][c + 1]; I[h * (LH / 2) + k + 1][c + 1] = s; }
+        }
+        __syncthreads();
+        if (c < LW && h == 1) {
             const unsigned add = I[LH / 2][c + 1];
             for (int k = 0; k < LH / 2; k++) I[LH / 2 + k + 1][c + 1] += add;
         }
